@@ -1,0 +1,98 @@
+"""ctypes mirror of include/cpe.h (the C ABI).  Pure data definitions: no compute lives here."""
+import ctypes as C
+
+MAX_LINKS = 20
+MAX_MARKERS = 32
+MAX_CAMS = 8
+MAX_JOINTS = 16
+MAX_BOUNDS = 32
+MAX_NQ = 3 + 3 * MAX_LINKS
+MAX_GMM = 8
+NX = 28
+MAX_WINDOW = 4
+
+OK, MAX_ITER, NUMERICAL, BAD_ARG, NO_DEVICE, HIP_ERROR = 0, 1, 2, -1, -2, -3
+JOINT_REVOLUTE_Y, JOINT_HOOKE_YZ = 0, 1
+CAM_FISHEYE, CAM_PINHOLE = 0, 1
+
+d3 = C.c_double * 3
+
+
+class Skeleton(C.Structure):
+    _fields_ = [
+        ("n_links", C.c_int32), ("n_markers", C.c_int32), ("n_joints", C.c_int32), ("n_bounds", C.c_int32),
+        ("parent", C.c_int32 * MAX_LINKS),
+        ("attach", d3 * MAX_LINKS),
+        ("com", d3 * MAX_LINKS),
+        ("mass", C.c_double * MAX_LINKS),
+        ("marker_link", C.c_int32 * MAX_MARKERS),
+        ("marker_off", d3 * MAX_MARKERS),
+        ("joint_parent", C.c_int32 * MAX_JOINTS),
+        ("joint_child", C.c_int32 * MAX_JOINTS),
+        ("joint_kind", C.c_int32 * MAX_JOINTS),
+        ("bound_a", C.c_int32 * MAX_BOUNDS),
+        ("bound_b", C.c_int32 * MAX_BOUNDS),
+        ("bound_lo", C.c_double * MAX_BOUNDS),
+        ("bound_up", C.c_double * MAX_BOUNDS),
+        ("motion_w", C.c_double * MAX_NQ),
+        ("rel_ref", C.c_int32 * MAX_NQ),
+        ("rel_sign", C.c_double * MAX_NQ),
+    ]
+
+    @property
+    def nq(self):
+        return 3 + 3 * self.n_links
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("_pad", C.c_int32),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("D", C.c_double * 4), ("R", C.c_double * 9), ("t", C.c_double * 3), ("mult", C.c_double),
+    ]
+
+
+class Priors(C.Structure):
+    _fields_ = [
+        ("gmm_k", C.c_int32), ("gmm_dim", C.c_int32),
+        ("gmm_logw", C.c_double * MAX_GMM),
+        ("gmm_mu", (C.c_double * NX) * MAX_GMM),
+        ("gmm_P", ((C.c_double * NX) * NX) * MAX_GMM),
+        ("lr_window", C.c_int32), ("_pad", C.c_int32),
+        ("lr_coef", (C.c_double * (MAX_WINDOW * NX)) * NX),
+        ("lr_b", C.c_double * NX),
+        ("lr_w", C.c_double * NX),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("h", C.c_double), ("loss_a", C.c_double), ("loss_b", C.c_double), ("loss_c", C.c_double),
+        ("cost_scale", C.c_double), ("bound_penalty", C.c_double), ("lambda0", C.c_double),
+        ("tol_step", C.c_double), ("tol_cost", C.c_double),
+        ("max_iter", C.c_int32), ("curvature", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("iterations", C.c_int32),
+        ("cost", C.c_double), ("cost_meas", C.c_double), ("cost_model", C.c_double),
+        ("cost_pose", C.c_double), ("cost_motion", C.c_double),
+        ("lam", C.c_double), ("max_constraint", C.c_double),
+    ]
+
+
+def default_options(fps: float = 120.0) -> Options:
+    """Same defaults as cpe_default_options() in csrc/cpe_api.cpp."""
+    o = Options()
+    o.h = 1.0 / fps
+    o.loss_a, o.loss_b, o.loss_c = 3.0, 10.0, 20.0   # acinoset_misc.py:479-481
+    o.cost_scale = 1e-3                              # acinoset_opt.py:602
+    o.bound_penalty = 1e6
+    o.lambda0 = 1e-3
+    o.tol_step = 1e-8
+    o.tol_cost = 1e-12
+    o.max_iter = 200
+    o.curvature = 0
+    return o

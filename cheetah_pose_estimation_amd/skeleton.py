@@ -1,0 +1,223 @@
+"""Cheetah skeleton definition: the host-side mirror of cheetah.py:109-200 (`model`), :19-106
+(`define_leg`), :203-356 (`add_pyomo_constraints`) and acinoset_misc.py:1581-1659 (`get_pose_state`),
+expressed as plain tables for the C ABI (include/cpe.h `cpe_skeleton`).
+
+Geometry conventions are the ones of SURVEY.md Appendix A.2/A.3/A.6: every link carries absolute ZYX
+Euler angles; "-x" links (base, bodyF, neck) extend along -x, "+x" links (tails) along +x, "-z" links
+(legs) along -z of their own frame.
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+from . import abi
+
+LINKS = ["base", "bodyF", "neck", "tail0", "tail1", "UFL", "LFL", "HFL", "UFR", "LFR", "HFR",
+         "UBL", "LBL", "UBR", "LBR", "HBL", "HBR"]            # cheetah.py:197-198
+PARENT = {"base": None, "bodyF": "base", "neck": "bodyF", "tail0": "base", "tail1": "tail0",
+          "UFL": "bodyF", "LFL": "UFL", "HFL": "LFL", "UFR": "bodyF", "LFR": "UFR", "HFR": "LFR",
+          "UBL": "base", "LBL": "UBL", "HBL": "LBL", "UBR": "base", "LBR": "UBR", "HBR": "LBR"}
+MARKERS = ["nose", "r_eye", "l_eye", "neck_base", "spine", "tail_base", "tail1", "tail2",
+           "r_shoulder", "r_front_knee", "r_front_ankle", "r_front_paw",
+           "l_shoulder", "l_front_knee", "l_front_ankle", "l_front_paw",
+           "r_hip", "r_back_knee", "r_back_ankle", "r_back_paw",
+           "l_hip", "l_back_knee", "l_back_ankle", "l_back_paw"]  # acinoset_misc.py:1914-1940
+# DLC column of each marker (acinoset_misc.py:1943-1969)
+DLC_INDEX = {"nose": 23, "r_eye": 0, "l_eye": 1, "neck_base": 24, "spine": 6, "tail_base": 22,
+             "tail1": 11, "tail2": 12, "l_shoulder": 13, "l_front_knee": 14, "l_front_ankle": 15,
+             "l_front_paw": 16, "r_shoulder": 2, "r_front_knee": 3, "r_front_ankle": 4,
+             "r_front_paw": 5, "l_hip": 17, "l_back_knee": 18, "l_back_ankle": 19, "l_back_paw": 20,
+             "r_hip": 7, "r_back_knee": 8, "r_back_ankle": 9, "r_back_paw": 10}
+
+# measurement standard deviations R (acinoset_misc.py:1762-1790); weight = 1/(2 R) (:1850, :231)
+R_MEAS = np.array([1.2, 1.24, 1.18, 2.08, 2.04, 2.52, 2.73, 1.83, 3.47, 2.75, 2.69, 2.24, 3.4, 2.91,
+                   2.85, 2.27, 3.26, 2.76, 2.33, 2.4, 3.53, 2.69, 2.49, 2.34])
+# constant-acceleration model standard deviations Q (acinoset_misc.py:1852-1907)
+Q_MODEL = np.array([4, 7, 5, 13, 9, 26, 10, 53, 34, 32, 18, 12, 0, 90, 43, 0, 118, 51, 0, 247, 0, 0,
+                    186, 0, 0, 91, 0, 0, 194, 0, 0, 164, 0, 0, 91, 0, 0, 295, 0, 0, 243, 0, 0, 334, 0,
+                    0, 149, 0, 0, 132, 0, 0, 132, 0], dtype=float)
+
+_PARAMS_JSON = os.path.join(os.path.dirname(__file__), "data", "skeleton_params.json")
+PHI, THETA, PSI = 0, 1, 2
+
+
+def dof(link: str, angle: int) -> int:
+    return 3 + 3 * LINKS.index(link) + angle
+
+
+def load_params(animal: str) -> dict:
+    """Link mass/length/radius exported from cheetah_params.py (tools/export_skeleton_params.py).
+    Animal naming follows acinoset_opt.py:455-457."""
+    with open(_PARAMS_JSON) as f:
+        allp = json.load(f)
+    if animal.endswith("-02"):
+        animal = animal[:-3]
+    if animal not in allp:
+        animal = "acinoset"
+    return allp[animal]
+
+
+def _link_param(p: dict, name: str) -> dict:
+    if name == "base":
+        return p["body_B"]
+    if name == "bodyF":
+        return p["body_F"]
+    if name in ("neck", "tail0", "tail1"):
+        return p[name]
+    seg = {"U": "thigh", "L": "calf", "H": "hock"}[name[0]]
+    return p["front" if name[1] == "F" else "back"][seg]
+
+
+def measurement_sigma(n_markers: int = 24, kinetic_dataset: bool = False) -> np.ndarray:
+    """R_pw[0] of get_uncertainty_models(): 2*R (acinoset_misc.py:1850); 7 for the kinetic dataset
+    (:187-188).  An extra 25th marker (benchmark only) reuses the `spine` value."""
+    R = 2.0 * R_MEAS
+    if kinetic_dataset:
+        R = np.full(24, 7.0)
+    if n_markers > 24:
+        R = np.concatenate([R, np.full(n_markers - 24, R[4])])
+    return R[:n_markers]
+
+
+def build_skeleton(animal: str = "phantom", n_markers: int = 24, kinetic_dataset: bool = False) -> abi.Skeleton:
+    p = load_params(animal)
+    L = {n: _link_param(p, n)["length"] for n in LINKS}
+    r = {n: _link_param(p, n)["radius"] for n in LINKS}
+    m = {n: _link_param(p, n)["mass"] for n in LINKS}
+    sk = abi.Skeleton()
+    sk.n_links = len(LINKS)
+    # link-local end points
+    bottom, top, com = {}, {}, {}
+    for n in LINKS:
+        if n == "base":
+            top[n], bottom[n], com[n] = (L[n] / 2, 0, 0), (-L[n] / 2, 0, 0), (0, 0, 0)
+        elif n in ("bodyF", "neck"):
+            top[n], bottom[n], com[n] = (0, 0, 0), (-L[n], 0, 0), (-L[n] / 2, 0, 0)
+        elif n in ("tail0", "tail1"):
+            top[n], bottom[n], com[n] = (0, 0, 0), (L[n], 0, 0), (L[n] / 2, 0, 0)
+        else:
+            top[n], bottom[n], com[n] = (0, 0, 0), (0, 0, -L[n]), (0, 0, -L[n] / 2)
+    attach = {"base": (0, 0, 0), "bodyF": bottom["base"], "neck": bottom["bodyF"], "tail0": top["base"],
+              "tail1": bottom["tail0"]}
+    for side, sy in (("L", -1.0), ("R", 1.0)):
+        # cheetah.py:32-38: start = body.Pb_I + Rb_I [ -+L/2, +-r, 0 ]; Pb_I of bodyF is its own com point
+        attach["UF" + side] = (com["bodyF"][0] - L["bodyF"] / 2, sy * r["bodyF"], 0)
+        attach["UB" + side] = (L["base"] / 2, sy * r["base"], 0)
+        for fb in "FB":
+            attach["L" + fb + side] = bottom["U" + fb + side]
+            attach["H" + fb + side] = bottom["L" + fb + side]
+    for i, n in enumerate(LINKS):
+        sk.parent[i] = -1 if PARENT[n] is None else LINKS.index(PARENT[n])
+        for d in range(3):
+            sk.attach[i][d] = attach[n][d]
+            sk.com[i][d] = com[n][d]
+        sk.mass[i] = m[n]
+
+    def add(a, b):
+        return tuple(x + y for x, y in zip(a, b))
+
+    # marker = (link, body-frame offset)   acinoset_misc.py:1586-1659
+    mk = {
+        "nose": ("neck", add(bottom["neck"], (-0.055, 0, -0.055))),
+        "r_eye": ("neck", add(bottom["neck"], (0, 0.045, 0))),
+        "l_eye": ("neck", add(bottom["neck"], (0, -0.045, 0))),
+        "neck_base": ("bodyF", bottom["bodyF"]),                 # neck.top
+        "spine": ("base", bottom["base"]),
+        "tail_base": ("base", top["base"]),
+        "tail1": ("tail0", bottom["tail0"]),                     # tail1.top
+        "tail2": ("tail1", bottom["tail1"]),
+        "r_shoulder": ("bodyF", add(bottom["bodyF"], (0.06, 0.075, -0.15))),
+        "l_shoulder": ("bodyF", add(bottom["bodyF"], (0.06, -0.075, -0.15))),
+        "r_hip": ("base", add(top["base"], (-0.06, 0.06, -0.1))),
+        "l_hip": ("base", add(top["base"], (-0.06, -0.06, -0.1))),
+    }
+    for side, s in (("r", "R"), ("l", "L")):
+        for fb, FB in (("front", "F"), ("back", "B")):
+            mk[f"{side}_{fb}_knee"] = ("U" + FB + s, bottom["U" + FB + s])
+            mk[f"{side}_{fb}_ankle"] = ("L" + FB + s, bottom["L" + FB + s])   # hock.top
+            mk[f"{side}_{fb}_paw"] = ("H" + FB + s, bottom["H" + FB + s])
+    names = list(MARKERS)
+    if n_markers > 24:
+        for e in range(n_markers - 24):
+            names.append(f"extra{e}")
+            mk[f"extra{e}"] = ("base", (0, 0, 0))   # benchmark-only 25th marker at the base COM
+    sk.n_markers = n_markers
+    for l, n in enumerate(names[:n_markers]):
+        sk.marker_link[l] = LINKS.index(mk[n][0])
+        for d in range(3):
+            sk.marker_off[l][d] = mk[n][1][d]
+
+    # joints (cheetah.py:71-72,101,160-161), parents before children
+    joints = [("base", "UBL", 0), ("base", "UBR", 0), ("bodyF", "UFL", 0), ("bodyF", "UFR", 0),
+              ("UFL", "LFL", 0), ("LFL", "HFL", 0), ("UFR", "LFR", 0), ("LFR", "HFR", 0),
+              ("UBL", "LBL", 0), ("LBL", "HBL", 0), ("UBR", "LBR", 0), ("LBR", "HBR", 0),
+              ("base", "tail0", 1), ("tail0", "tail1", 1)]
+    sk.n_joints = len(joints)
+    for j, (a, b, k) in enumerate(joints):
+        sk.joint_parent[j], sk.joint_child[j], sk.joint_kind[j] = LINKS.index(a), LINKS.index(b), k
+
+    # bounds lo <= q_a - q_b <= up (cheetah.py:306-352)
+    pi = math.pi
+    B = []
+    if kinetic_dataset:
+        B += [("neck", PSI, "bodyF", -0.05, 0.05), ("neck", PHI, "bodyF", -0.05, 0.05),
+              ("base", PHI, None, -0.05, 0.05), ("bodyF", PSI, "base", -0.1, 0.1),
+              ("bodyF", PHI, "base", -0.1, 0.1), ("base", PSI, "tail0", -0.1, 0.1)]
+    else:
+        B += [("neck", PSI, "bodyF", -pi / 6, pi / 6), ("neck", PHI, "bodyF", -pi / 6, pi / 6),
+              ("base", PHI, None, -pi / 6, pi / 6), ("bodyF", PSI, "base", -pi / 6, pi / 6),
+              ("bodyF", PHI, "base", -pi / 6, pi / 6), ("base", PSI, "tail0", -pi / 1.5, pi / 1.5)]
+    B += [("neck", THETA, "bodyF", -pi / 6, pi / 6), ("bodyF", THETA, "base", -pi / 6, pi / 6),
+          ("base", THETA, "tail0", -pi / 1.5, pi / 1.5), ("tail0", THETA, "tail1", -pi / 1.5, pi / 1.5),
+          ("tail0", PSI, "tail1", -pi / 1.5, pi / 1.5)]
+    for body, thigh, calf, hock, back in (("bodyF", "UFL", "LFL", "HFL", False), ("bodyF", "UFR", "LFR", "HFR", False),
+                                          ("base", "UBL", "LBL", "HBL", True), ("base", "UBR", "LBR", "HBR", True)):
+        B.append((body, THETA, thigh, -0.75 * pi, 0.75 * pi))
+        B.append((thigh, THETA, calf, *((0.0, pi) if back else (-pi, 0.0))))
+        B.append((calf, THETA, hock, *((-0.75 * pi, 0.0) if back else (-pi / 4, 0.75 * pi))))
+    sk.n_bounds = len(B)
+    for i, (a, ang, b, lo, up) in enumerate(B):
+        sk.bound_a[i] = dof(a, ang)
+        sk.bound_b[i] = -1 if b is None else dof(b, ang)
+        sk.bound_lo[i], sk.bound_up[i] = lo, up
+
+    for pidx in range(sk.nq):
+        sk.motion_w[pidx] = 0.0 if Q_MODEL[pidx] == 0 else 1.0 / Q_MODEL[pidx] ** 2
+        sk.rel_ref[pidx] = -1
+        sk.rel_sign[pidx] = 1.0
+    # relative angles (acinoset_misc.py:510-526)
+    for n in LINKS[1:]:
+        par = PARENT[n]
+        for a in range(3):
+            sk.rel_ref[dof(n, a)] = dof(par, a)
+            sk.rel_sign[dof(n, a)] = 1.0 if n in ("bodyF", "neck") else -1.0
+    return sk
+
+
+def independent_dofs(sk: abi.Skeleton) -> np.ndarray:
+    dep = set()
+    for j in range(sk.n_joints):
+        c = sk.joint_child[j]
+        dep.add(3 + 3 * c)
+        if sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y:
+            dep.add(3 + 3 * c + 2)
+    return np.array([p for p in range(sk.nq) if p not in dep], dtype=np.int32)
+
+
+def jacobian_layout(sk: abi.Skeleton):
+    """(slot_marker, slot_dof): the structurally non-zero (marker, dof) pairs, marker-major; within a
+    marker: x, y, z, then the 3 angles of each link on the path root -> marker link."""
+    sm, sd = [], []
+    for l in range(sk.n_markers):
+        chain = []
+        k = sk.marker_link[l]
+        while k >= 0:
+            chain.append(k)
+            k = sk.parent[k]
+        chain.reverse()
+        dofs = [0, 1, 2] + [3 + 3 * k + a for k in chain for a in range(3)]
+        sm += [l] * len(dofs)
+        sd += dofs
+    return np.array(sm, dtype=np.int32), np.array(sd, dtype=np.int32)

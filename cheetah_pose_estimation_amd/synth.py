@@ -1,0 +1,202 @@
+"""Synthetic benchmark sequences: a galloping-cheetah-like trajectory of the
+17-link skeleton seen by C fisheye cameras modelled on the AcinoSet GoPro calibration, with DLC-like
+noise, outliers and likelihood drop-outs.  Data generation only (numpy, host): nothing here is on the
+solve path, and nothing is read from the reference at run time.
+"""
+import math
+
+import numpy as np
+
+from . import abi
+from .skeleton import LINKS, dof, PHI, THETA, PSI, measurement_sigma, independent_dofs
+
+IMG_W, IMG_H = 2704, 1520
+
+
+# ---------------------------------------------------------------------------------------------------
+def rot_zyx(ang: np.ndarray) -> np.ndarray:
+    """ang[..., 3] = (phi, theta, psi) -> R[..., 3, 3] = Rz(psi) Ry(theta) Rx(phi)."""
+    sf, cf = np.sin(ang[..., 0]), np.cos(ang[..., 0])
+    st, ct = np.sin(ang[..., 1]), np.cos(ang[..., 1])
+    sp, cp = np.sin(ang[..., 2]), np.cos(ang[..., 2])
+    R = np.empty(ang.shape[:-1] + (3, 3))
+    R[..., 0, 0] = cp * ct; R[..., 0, 1] = sf * st * cp - sp * cf; R[..., 0, 2] = sf * sp + st * cf * cp
+    R[..., 1, 0] = sp * ct; R[..., 1, 1] = sf * sp * st + cf * cp; R[..., 1, 2] = -sf * cp + sp * st * cf
+    R[..., 2, 0] = -st;     R[..., 2, 1] = sf * ct;                R[..., 2, 2] = cf * ct
+    return R
+
+
+def fk_numpy(sk: abi.Skeleton, q: np.ndarray):
+    """q[..., nq] -> (positions[..., L, 3], com[..., 3])."""
+    nl = sk.n_links
+    R = rot_zyx(q[..., 3:].reshape(q.shape[:-1] + (nl, 3)))
+    origin = [None] * nl
+    for i in range(nl):
+        if sk.parent[i] < 0:
+            origin[i] = q[..., 0:3]
+        else:
+            p = sk.parent[i]
+            origin[i] = origin[p] + R[..., p, :, :] @ np.array(sk.attach[i][:])
+    pos = np.stack([origin[sk.marker_link[l]] + R[..., sk.marker_link[l], :, :] @ np.array(sk.marker_off[l][:])
+                    for l in range(sk.n_markers)], axis=-2)
+    M = sum(sk.mass[i] for i in range(nl))
+    com = sum(sk.mass[i] * (origin[i] + R[..., i, :, :] @ np.array(sk.com[i][:])) for i in range(nl)) / M
+    return pos, com
+
+
+def project_numpy(cam: abi.Camera, p: np.ndarray) -> np.ndarray:
+    """p[..., 3] -> uv[..., 2]; fisheye / pinhole of acinoset_misc.py:1663-1696."""
+    Rc = np.array(cam.R[:]).reshape(3, 3)
+    X = p @ Rc.T + np.array(cam.t[:])
+    a, b = X[..., 0] / X[..., 2], X[..., 1] / X[..., 2]
+    r = np.sqrt(a * a + b * b)
+    D = cam.D
+    if cam.model == abi.CAM_FISHEYE:
+        th = np.arctan(r)
+        thd = th * (1 + D[0] * th**2 + D[1] * th**4 + D[2] * th**6 + D[3] * th**8)
+        g = thd / (r + 1e-12)
+    else:
+        g = 1 + D[0] * r**2 + D[1] * r**4 + D[2] * r**6
+    return np.stack([cam.fx * a * g + cam.cx, cam.fy * b * g + cam.cy], axis=-1), X[..., 2]
+
+
+def project_dependents_numpy(sk: abi.Skeleton, q: np.ndarray) -> np.ndarray:
+    """Closed-form solve of the joint equalities for the dependent angles; q[..., nq]."""
+    q = q.copy()
+    for j in range(sk.n_joints):
+        p, c = sk.joint_parent[j], sk.joint_child[j]
+        Rp = rot_zyx(q[..., 3 + 3 * p:6 + 3 * p])
+        ax, ay, az = Rp[..., 0, 1], Rp[..., 1, 1], Rp[..., 2, 1]
+        th = q[..., 3 + 3 * c + 1]
+        st, ct = np.sin(th), np.cos(th)
+        if sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y:
+            sphi = np.clip(az / ct, -1, 1)
+            phi = np.arcsin(sphi)
+            psi = np.arctan2(ay, ax) - np.arctan2(np.cos(phi), sphi * st)
+            ref = q[..., 3 + 3 * p + 2]
+            psi = psi + 2 * np.pi * np.round((ref - psi) / (2 * np.pi))
+            q[..., 3 + 3 * c], q[..., 3 + 3 * c + 2] = phi, psi
+        else:
+            psi = q[..., 3 + 3 * c + 2]
+            sp, cp = np.sin(psi), np.cos(psi)
+            q[..., 3 + 3 * c] = np.arctan2(ax * st * cp + ay * st * sp + az * ct, ay * cp - ax * sp)
+    return q
+
+
+# ---------------------------------------------------------------------------------------------------
+def look_at_camera(pos, target, fx, fy, cx, cy, D, model=abi.CAM_FISHEYE, mult=1.0) -> abi.Camera:
+    pos, target = np.asarray(pos, float), np.asarray(target, float)
+    fwd = target - pos
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0, 0, 1.0])
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    Rc = np.stack([right, down, fwd])          # world -> camera
+    cam = abi.Camera()
+    cam.model = model
+    cam.fx, cam.fy, cam.cx, cam.cy = fx, fy, cx, cy
+    for i in range(4):
+        cam.D[i] = D[i]
+    for i in range(9):
+        cam.R[i] = Rc.reshape(-1)[i]
+    t = -Rc @ pos
+    for i in range(3):
+        cam.t[i] = t[i]
+    cam.mult = mult
+    return cam
+
+
+def make_cameras(n_cams: int = 6, seed: int = 1234, track: float = 20.0):
+    """3 cameras per side of a `track`-m straight, 4 m lateral, 0.5-1.0 m high, looking at the track
+    centre; intrinsics = the AcinoSet GoPro calibration recovered in SURVEY 8c-5, each +-1 %."""
+    rng = np.random.default_rng(seed)
+    cams = (abi.Camera * n_cams)()
+    D0 = np.array([0.0366, 0.0480, -0.0347, 0.0074])
+    for c in range(n_cams):
+        side = 1.0 if c % 2 == 0 else -1.0
+        x = track * (0.15 + 0.35 * (c // 2)) if n_cams > 1 else track / 2
+        pos = [x, side * 4.0, rng.uniform(0.5, 1.0)]
+        s = rng.uniform(0.99, 1.01, 4)
+        cams[c] = look_at_camera(pos, [x + rng.uniform(-1, 1), 0.0, 0.4], 1241.84 * s[0], 1239.92 * s[1],
+                                 1346.96 * s[2], 773.02 * s[3], D0 * rng.uniform(0.8, 1.2, 4))
+    return cams
+
+
+def truth_trajectory(sk: abi.Skeleton, N: int, fps: float, rng: np.random.Generator, speed: float = 12.0):
+    """Ground-truth q[N, nq]: base x = speed*t, z = 0.55 + 0.03 sin(2 pi 3 t), limb pitch sinusoids at
+    3 Hz inside the reference's joint ranges (cheetah.py:333-352); limb roll/yaw from the joint
+    equalities."""
+    t = np.arange(N) / fps
+    w = 2 * math.pi * 3.0
+    q = np.zeros((N, sk.nq))
+    ph = rng.uniform(0, 2 * math.pi, 16)
+    amp = rng.uniform(0.8, 1.2, 16)
+    x0 = rng.uniform(0.0, 1.0)
+    q[:, 0] = x0 + speed * t
+    q[:, 1] = rng.uniform(-0.3, 0.3) + 0.2 * t
+    q[:, 2] = 0.55 + 0.03 * np.sin(w * t + ph[0])
+    # '-x' aligned body: the head points along -x of the base frame, so running towards +x means
+    # psi = pi + heading (acinoset_misc.py:454)
+    heading = math.pi + math.atan2(0.2, speed)
+    base_pitch = 0.08 * amp[1] * np.sin(w * t + ph[1])
+    q[:, dof("base", PHI)] = 0.03 * np.sin(w * t + ph[2])
+    q[:, dof("base", THETA)] = base_pitch
+    q[:, dof("base", PSI)] = heading + 0.03 * np.sin(0.5 * w * t + ph[3])
+    q[:, dof("bodyF", PHI)] = q[:, dof("base", PHI)] + 0.03 * np.sin(w * t + ph[4])
+    q[:, dof("bodyF", THETA)] = base_pitch - 0.15 * amp[2] * np.sin(w * t + ph[1])
+    q[:, dof("bodyF", PSI)] = q[:, dof("base", PSI)] + 0.04 * np.sin(0.5 * w * t + ph[5])
+    q[:, dof("neck", PHI)] = q[:, dof("bodyF", PHI)]
+    q[:, dof("neck", THETA)] = q[:, dof("bodyF", THETA)] + 0.2 + 0.05 * np.sin(w * t + ph[6])
+    q[:, dof("neck", PSI)] = q[:, dof("bodyF", PSI)]
+    q[:, dof("tail0", THETA)] = base_pitch + 0.3 + 0.2 * amp[3] * np.sin(w * t + ph[7])
+    q[:, dof("tail0", PSI)] = q[:, dof("base", PSI)] + 0.2 * np.sin(0.5 * w * t + ph[8])
+    q[:, dof("tail1", THETA)] = q[:, dof("tail0", THETA)] + 0.2 * np.sin(w * t + ph[9])
+    q[:, dof("tail1", PSI)] = q[:, dof("tail0", PSI)] + 0.2 * np.sin(0.5 * w * t + ph[10])
+    for i, (U, Lk, H, back, body) in enumerate((("UFL", "LFL", "HFL", False, "bodyF"), ("UFR", "LFR", "HFR", False, "bodyF"),
+                                                ("UBL", "LBL", "HBL", True, "base"), ("UBR", "LBR", "HBR", True, "base"))):
+        p0 = ph[11 + i]
+        thU = 0.45 * amp[11 + i] * np.sin(w * t + p0)
+        if back:
+            thL = thU - 0.45 - 0.3 * np.sin(w * t + p0 + 0.8)         # thigh - calf in [0.15, 0.75]
+            thH = thL + 0.5 + 0.3 * np.sin(w * t + p0 + 1.6)          # calf - hock in [-0.8, -0.2]
+        else:
+            thL = thU + 0.45 + 0.3 * np.sin(w * t + p0 + 0.8)         # thigh - calf in [-0.75, -0.15]
+            thH = thL - 0.3 - 0.3 * np.sin(w * t + p0 + 1.6)          # calf - hock in [0, 0.6]
+        for n, th in ((U, thU), (Lk, thL), (H, thH)):
+            q[:, dof(n, THETA)] = th
+            q[:, dof(n, PSI)] = q[:, dof(body, PSI)]
+    return project_dependents_numpy(sk, q)
+
+
+def make_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0, seed: int = 1234,
+               noise_px: float = 2.0, outlier_frac: float = 0.10, init_noise: float = 0.05,
+               dlc_thresh: float = 0.5, kinetic_dataset: bool = False):
+    """B independent sequences (sequence b uses seed + b).  Returns dict of C-contiguous fp64 arrays:
+    q_true, q_init [B,N,nq]; meas [B,N,C,L,2]; weight [B,N,C,L]."""
+    C, L, nq = len(cams), sk.n_markers, sk.nq
+    q_true = np.empty((B, N, nq)); q_init = np.zeros((B, N, nq))
+    meas = np.empty((B, N, C, L, 2)); weight = np.empty((B, N, C, L))
+    sigma = measurement_sigma(L, kinetic_dataset)
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        qt = truth_trajectory(sk, N, fps, rng)
+        q_true[b] = qt
+        pos, _ = fk_numpy(sk, qt)
+        for c in range(C):
+            uv, z = project_numpy(cams[c], pos)
+            uv = uv + rng.normal(0, noise_px, uv.shape)
+            out = rng.random((N, L)) < outlier_frac
+            uv[out] = np.stack([rng.uniform(0, IMG_W, out.sum()), rng.uniform(0, IMG_H, out.sum())], axis=-1)
+            lik = rng.random((N, L))
+            vis = (z > 0.1) & (uv[..., 0] >= 0) & (uv[..., 0] < IMG_W) & (uv[..., 1] >= 0) & (uv[..., 1] < IMG_H)
+            wgt = np.where((lik > dlc_thresh) & vis, 1.0 / sigma[None, :], 0.0)    # acinoset_misc.py:231
+            uv[~vis] = 0.0
+            meas[b, :, c] = uv
+            weight[b, :, c] = wgt
+        # reference initial guess (acinoset_opt.py:574-583): all angles 0, psi = heading for every link
+        dx = np.diff(qt[:, 0]); dy = np.diff(qt[:, 1])
+        psi = np.arctan2(dy, dx); psi = np.pi + np.append(psi, psi[-1])   # acinoset_misc.py:450-454
+        q_init[b, :, 0:3] = qt[:, 0:3] + rng.normal(0, init_noise, (N, 3))
+        for i in range(sk.n_links):
+            q_init[b, :, 3 + 3 * i + 2] = psi
+    return dict(q_true=q_true, q_init=q_init, meas=np.ascontiguousarray(meas), weight=np.ascontiguousarray(weight))

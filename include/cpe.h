@@ -1,0 +1,194 @@
+/*
+ * cpe.h -- C ABI of the MI355X trajectory-optimisation back end for cheetah 3D pose.
+ *
+ * This is the drop-in boundary.  The reference (zicodasilva/cheetah_pose_estimation) has no FFI: its
+ * seam is the hand-off of the Pyomo model to the IPOPT executable,
+ *     pe.utils.default_solver(...).solve(robot.m)          acinoset_opt.py:611-617
+ * plus the model-building calls around it (acinoset_opt.py:413-536, :539-635).  The entry points below
+ * are what a ctypes binding placed at that seam binds.  Plain pointers and sizes,
+ * caller-owned buffers, integer status codes, no torch types.
+ *
+ * Conventions:
+ *   - q[54] = [x,y,z,phi,theta,psi]_base then [phi,theta,psi] of links 1..16, absolute ZYX Euler angles;
+ *     link order base,bodyF,neck,tail0,tail1,UFL,LFL,HFL,UFR,LFR,HFR,UBL,LBL,UBR,LBR,HBL,HBR
+ *     (cheetah.py:197-198).  DOF index of angle j of link i is 3 + 3*i + j.
+ *   - all arrays are C-contiguous fp64, frames are the slowest index inside a sequence:
+ *     q[B][N][nq], meas[B][N][C][L][2], weight[B][N][C][L].
+ *   - "device" entry points take pointers into HBM (e.g. torch-ROCm tensor.data_ptr()); the *_host
+ *     variants take host pointers and stage through HBM (PCIe-inclusive).
+ */
+#ifndef CPE_H
+#define CPE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPE_MAX_LINKS 20
+#define CPE_MAX_MARKERS 32
+#define CPE_MAX_CAMS 8
+#define CPE_MAX_JOINTS 16
+#define CPE_MAX_BOUNDS 32
+#define CPE_MAX_NQ (3 + 3 * CPE_MAX_LINKS)
+#define CPE_MAX_GMM 8        /* mixture components of the pose prior */
+#define CPE_NX 28            /* size of the reduced / relative-angle vector x (acinoset_misc.py:1699-1757) */
+#define CPE_MAX_WINDOW 4     /* window of the linear motion prior (acinoset_opt.py:545) */
+
+typedef int32_t cpe_status;
+#define CPE_OK 0              /* converged                                             */
+#define CPE_MAX_ITER 1        /* iteration limit reached (solution still written)      */
+#define CPE_NUMERICAL 2       /* numerical failure (non-finite cost / factorisation)   */
+#define CPE_BAD_ARG (-1)
+#define CPE_NO_DEVICE (-2)    /* HIP runtime / GPU unavailable: there is NO CPU fallback */
+#define CPE_HIP_ERROR (-3)
+
+/* joint kinds (cheetah.py:71-72,101,160-161): the equalities live in the .robot `angle_constraints` */
+#define CPE_JOINT_REVOLUTE_Y 0   /* (R_p e_y).(R_c e_x) = 0 and (R_p e_y).(R_c e_z) = 0 ; child phi,psi dependent */
+#define CPE_JOINT_HOOKE_YZ 1     /* (R_p e_y).(R_c e_z) = 0                            ; child phi dependent     */
+
+/* camera models (acinoset_misc.py:1663-1696) */
+#define CPE_CAM_FISHEYE 0
+#define CPE_CAM_PINHOLE 1
+
+/*
+ * Skeleton = absolute-orientation articulated chain.  Every point of the body is
+ *     x_base + sum_{k on the path root->link} R_k(q) * v_k
+ * origin_i = origin_parent(i) + R_parent(i) * attach[i]   (origin_base = q[0:3])
+ * com_i    = origin_i + R_i * com[i]                      (Link3D.Pb_I)
+ * marker_l = origin_link(l) + R_link(l) * marker_off[l]   (acinoset_misc.py:1586-1659)
+ */
+typedef struct cpe_skeleton {
+    int32_t n_links;
+    int32_t n_markers;
+    int32_t n_joints;
+    int32_t n_bounds;
+    int32_t parent[CPE_MAX_LINKS];
+    double attach[CPE_MAX_LINKS][3];
+    double com[CPE_MAX_LINKS][3];
+    double mass[CPE_MAX_LINKS];
+    int32_t marker_link[CPE_MAX_MARKERS];
+    double marker_off[CPE_MAX_MARKERS][3];
+    int32_t joint_parent[CPE_MAX_JOINTS];
+    int32_t joint_child[CPE_MAX_JOINTS];
+    int32_t joint_kind[CPE_MAX_JOINTS];
+    /* lo <= q[a] - q[b] <= up ; b < 0 means a plain bound on q[a]   (cheetah.py:306-352) */
+    int32_t bound_a[CPE_MAX_BOUNDS];
+    int32_t bound_b[CPE_MAX_BOUNDS];
+    double bound_lo[CPE_MAX_BOUNDS];
+    double bound_up[CPE_MAX_BOUNDS];
+    /* constant-acceleration model weight 1/Q_p^2, 0 where Q_p = 0 (acinoset_misc.py:234,1852-1908) */
+    double motion_w[CPE_MAX_NQ];
+    /* relative angles (acinoset_misc.py:508-528): rel[p] = rel_sign[p] * (q[p] - q[rel_ref[p]]),
+     * rel_ref[p] < 0 means rel[p] = q[p].  x (28) = rel restricted to the independent dofs. */
+    int32_t rel_ref[CPE_MAX_NQ];
+    double rel_sign[CPE_MAX_NQ];
+} cpe_skeleton;
+
+typedef struct cpe_camera {
+    int32_t model;      /* CPE_CAM_FISHEYE | CPE_CAM_PINHOLE */
+    int32_t _pad;
+    double fx, fy, cx, cy;
+    double D[4];        /* fisheye k1..k4 ; pinhole uses D[0..2] */
+    double R[9];        /* row-major world->camera rotation */
+    double t[3];
+    double mult;        /* cam_uncertainty_multiplier (acinoset_misc.py:462-464) */
+} cpe_camera;
+
+/* learned priors of the monocular "data-driven" model (config 3) */
+typedef struct cpe_priors {
+    int32_t gmm_k;                                   /* 0 = pose prior off (acinoset_misc.py:680-714) */
+    int32_t gmm_dim;                                 /* 22 = x[6:]                                    */
+    double gmm_logw[CPE_MAX_GMM];                    /* log(w_k) - 0.5*logdet(2 pi Sigma_k)           */
+    double gmm_mu[CPE_MAX_GMM][CPE_NX];
+    double gmm_P[CPE_MAX_GMM][CPE_NX][CPE_NX];       /* precision matrices Sigma_k^-1                 */
+    int32_t lr_window;                               /* 0 = motion prior off (acinoset_misc.py:291-336) */
+    int32_t _pad;
+    double lr_coef[CPE_NX][CPE_MAX_WINDOW * CPE_NX]; /* y = coef . [x_{n-w};...;x_{n-1}] + b, oldest first */
+    double lr_b[CPE_NX];
+    double lr_w[CPE_NX];                             /* 1/error_variance (0 if variance is 0)         */
+} cpe_priors;
+
+typedef struct cpe_options {
+    double h;            /* 1/fps; implicit-Euler step of make_pyomo_model (acinoset_opt.py:508) */
+    double loss_a, loss_b, loss_c;  /* redescending loss knots 3,10,20 (acinoset_misc.py:479-481) */
+    double cost_scale;   /* 1e-3 (acinoset_opt.py:602); only scales the reported objective      */
+    double bound_penalty;/* weight of the quadratic penalty that enforces the 23 angle bounds   */
+    double lambda0;      /* initial Levenberg-Marquardt damping                                 */
+    double tol_step;     /* converged when max |du| < tol_step                                  */
+    double tol_cost;     /* ... or relative cost decrease < tol_cost                            */
+    int32_t max_iter;
+    int32_t curvature;   /* 0: IRLS weight rho'(s)/s ; 1: max(rho''(s),0) + small floor         */
+} cpe_options;
+
+typedef struct cpe_stats {
+    int32_t status;      /* cpe_status of this sequence */
+    int32_t iterations;  /* LM iterations (accepted + rejected) */
+    double cost;         /* final objective, already multiplied by cost_scale */
+    double cost_meas, cost_model, cost_pose, cost_motion;   /* estimator.costs (acinoset_opt.py:603-608) */
+    double lambda;       /* final damping */
+    double max_constraint; /* max |joint equality| at the solution */
+} cpe_stats;
+
+typedef struct cpe_handle cpe_handle;
+
+/* ---- life cycle -------------------------------------------------------------------------------- */
+/* replaces init_trajectory()'s model construction (acinoset_opt.py:459-525). `priors` may be NULL. */
+cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams,
+                      const cpe_options* opts, const cpe_priors* priors, int32_t device,
+                      cpe_handle** out);
+void cpe_destroy(cpe_handle* h);
+const char* cpe_last_error(void);
+void cpe_default_options(cpe_options* o);
+/* stream the handle launches on (hipStream_t as void*), for event timing by the caller */
+void* cpe_stream(cpe_handle* h);
+cpe_status cpe_synchronize(cpe_handle* h);
+
+/* number of structurally non-zero (marker, dof) Jacobian slots: sum_l (3 + 3*chain_len(l)) */
+int32_t cpe_jacobian_slots(const cpe_handle* h);
+/* slot -> (marker, dof) tables; caller provides int32[cpe_jacobian_slots] each */
+cpe_status cpe_jacobian_layout(const cpe_handle* h, int32_t* slot_marker, int32_t* slot_dof);
+int32_t cpe_num_independent(const cpe_handle* h);                      /* 28 */
+cpe_status cpe_independent_dofs(const cpe_handle* h, int32_t* dofs);   /* q index of each reduced coordinate */
+
+/* ---- metric 1: residual + Jacobian evaluation ------------------------------------------------------
+ * One pass of acinoset_misc.py:269-288 (pose + measurement constraints) and :639-677 (acceleration
+ * slack) over B*N frames; all pointers are DEVICE pointers.
+ *   r     [B][N][C][L][2]      reprojection residual  proj(q) - meas   (= slack_meas / fte.pickle meas_err)
+ *   J     [B][N][C][S][2]      d r / d q on the S structurally non-zero (marker,dof) slots
+ *   eps   [B][N][nq]           acceleration slack ddq_n - ddq_{n-1} (0 for n < 3, free initial states)
+ *   cost  [B][N]   (optional)  per-frame sum_c,l,d rho(mult*w*r)  (acinoset_misc.py:459-484), unscaled
+ */
+cpe_status cpe_eval_resjac(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas,
+                           const double* weight, double* r, double* J, double* eps, double* cost);
+
+/* ---- dependent-angle projection: closed-form solve of the 26 joint equalities for the 26 dependent
+ * angles given the 28 independent ones (in place on q[B][N][nq], device pointer). */
+cpe_status cpe_project_joints(cpe_handle* h, int32_t B, int32_t N, double* q);
+
+/* ---- metric 2: full-trajectory solve ---------------------------------------------------------------
+ * replaces default_solver(...).solve(robot.m) for the kinematic model (acinoset_opt.py:589-617).
+ * Device pointers.  q_init [B][N][nq] (dependent angles are re-projected), outputs as the reference
+ * saves them (acinoset_opt.py:289-361):
+ *   q,dq,ddq [B][N][nq] ; positions [B][N][L][3] ; meas_err [B][N][C][L][2] ; stats[B] (HOST pointer)
+ */
+cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas,
+                     const double* weight, double* q, double* dq, double* ddq, double* positions,
+                     double* meas_err, cpe_stats* stats);
+
+/* host-pointer convenience wrappers (stage through HBM; PCIe-inclusive) */
+cpe_status cpe_eval_resjac_host(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas,
+                                const double* weight, double* r, double* J, double* eps, double* cost);
+cpe_status cpe_solve_host(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas,
+                          const double* weight, double* q, double* dq, double* ddq, double* positions,
+                          double* meas_err, cpe_stats* stats);
+
+/* forward kinematics only (get_pose_state / get_com, acinoset_misc.py:1581-1659, :722-742); device ptrs */
+cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q,
+                                  double* positions /*[B][N][L][3]*/, double* com /*[B][N][3] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPE_H */

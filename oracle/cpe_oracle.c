@@ -1,0 +1,784 @@
+/*
+ * cpe_oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C, fp64, single thread) of the
+ * reference's full-trajectory-estimation hot path.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product (libcpe.so, HIP) never does.
+ *
+ * Parity status of this oracle (see DESIGN.md "Oracle"):
+ *   - projection, robust loss, uncertainty tables, relative angles: PINNED by golden vectors generated
+ *     from the reference's own functions (tests/golden/misc_golden.npz, tools/gen_golden.py).
+ *   - link parameters: PINNED (cheetah_params.py values exported by tools/export_skeleton_params.py).
+ *   - forward kinematics / marker model / joint equalities: restated from SURVEY.md Appendix A (the
+ *     FK library `physical_education` is absent from /root/reference and the stored .robot / fte.pickle
+ *     files are refused by the safe loaders): pinned only through tests/golden/fk_csv_pin (2D files).
+ *   - argmin of the full NLP vs the reference's IPOPT solutions: PARITY UNPINNED (IPOPT/Pyomo absent).
+ *
+ * What each function follows in the reference is cited at its definition.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/cpe.h"
+
+#define NQ(s) (3 + 3 * (s)->n_links)
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Rotation R = Rz(psi) Ry(theta) Rx(phi), row-major (Link3D.Rb_I in the .robot files) */
+void cpo_rot(const double a[3], double R[9]) {
+    double sf = sin(a[0]), cf = cos(a[0]), st = sin(a[1]), ct = cos(a[1]), sp = sin(a[2]), cp = cos(a[2]);
+    R[0] = cp * ct; R[1] = sf * st * cp - sp * cf; R[2] = sf * sp + st * cf * cp;
+    R[3] = sp * ct; R[4] = sf * sp * st + cf * cp; R[5] = -sf * cp + sp * st * cf;
+    R[6] = -st;     R[7] = sf * ct;                R[8] = cf * ct;
+}
+
+/* dR[j] = dR/d(angle j), j = phi,theta,psi */
+void cpo_drot(const double a[3], double dR[3][9]) {
+    double sf = sin(a[0]), cf = cos(a[0]), st = sin(a[1]), ct = cos(a[1]), sp = sin(a[2]), cp = cos(a[2]);
+    double* d = dR[0]; /* d/dphi */
+    d[0] = 0; d[1] = cf * st * cp + sp * sf; d[2] = cf * sp - st * sf * cp;
+    d[3] = 0; d[4] = cf * sp * st - sf * cp; d[5] = -cf * cp - sp * st * sf;
+    d[6] = 0; d[7] = cf * ct;                d[8] = -sf * ct;
+    d = dR[1]; /* d/dtheta */
+    d[0] = -cp * st; d[1] = sf * ct * cp; d[2] = ct * cf * cp;
+    d[3] = -sp * st; d[4] = sf * sp * ct; d[5] = sp * ct * cf;
+    d[6] = -ct;      d[7] = -sf * st;     d[8] = -cf * st;
+    d = dR[2]; /* d/dpsi */
+    d[0] = -sp * ct; d[1] = -sf * st * sp - cp * cf; d[2] = sf * cp - st * cf * sp;
+    d[3] = cp * ct;  d[4] = sf * cp * st - cf * sp;  d[5] = sf * sp + cp * st * cf;
+    d[6] = 0; d[7] = 0; d[8] = 0;
+}
+
+static void matvec3(const double* R, const double* v, double* out) {
+    for (int i = 0; i < 3; i++) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+
+/* FK chain: origin_i = origin_parent + R_parent * attach_i (cheetah.py:32-38,109-200) */
+void cpo_fk(const cpe_skeleton* s, const double* q, double* R /*[nl][9]*/, double* origin /*[nl][3]*/) {
+    for (int i = 0; i < s->n_links; i++) {
+        cpo_rot(q + 3 + 3 * i, R + 9 * i);
+        if (s->parent[i] < 0) {
+            for (int d = 0; d < 3; d++) origin[3 * i + d] = q[d];
+        } else {
+            int p = s->parent[i];
+            double v[3];
+            matvec3(R + 9 * p, s->attach[i], v);
+            for (int d = 0; d < 3; d++) origin[3 * i + d] = origin[3 * p + d] + v[d];
+        }
+    }
+}
+
+/* marker model (acinoset_misc.py:1581-1659, order = get_markers() :1914-1940) */
+void cpo_markers(const cpe_skeleton* s, const double* q, double* pos /*[L][3]*/) {
+    double R[CPE_MAX_LINKS * 9], o[CPE_MAX_LINKS * 3];
+    cpo_fk(s, q, R, o);
+    for (int l = 0; l < s->n_markers; l++) {
+        int k = s->marker_link[l];
+        double v[3];
+        matvec3(R + 9 * k, s->marker_off[l], v);
+        for (int d = 0; d < 3; d++) pos[3 * l + d] = o[3 * k + d] + v[d];
+    }
+}
+
+/* centre of mass (acinoset_misc.py:722-742) */
+void cpo_com(const cpe_skeleton* s, const double* q, double* com) {
+    double R[CPE_MAX_LINKS * 9], o[CPE_MAX_LINKS * 3], M = 0;
+    cpo_fk(s, q, R, o);
+    com[0] = com[1] = com[2] = 0;
+    for (int i = 0; i < s->n_links; i++) {
+        double v[3];
+        matvec3(R + 9 * i, s->com[i], v);
+        for (int d = 0; d < 3; d++) com[d] += s->mass[i] * (o[3 * i + d] + v[d]);
+        M += s->mass[i];
+    }
+    for (int d = 0; d < 3; d++) com[d] /= M;
+}
+
+/* markers + dense Jacobian d pos / d q  ([L][3][nq]) */
+void cpo_markers_jac(const cpe_skeleton* s, const double* q, double* pos, double* dpos) {
+    int nq = NQ(s);
+    double R[CPE_MAX_LINKS * 9], o[CPE_MAX_LINKS * 3];
+    cpo_fk(s, q, R, o);
+    memset(dpos, 0, sizeof(double) * s->n_markers * 3 * nq);
+    for (int l = 0; l < s->n_markers; l++) {
+        int k = s->marker_link[l];
+        double v[3];
+        matvec3(R + 9 * k, s->marker_off[l], v);
+        for (int d = 0; d < 3; d++) {
+            pos[3 * l + d] = o[3 * k + d] + v[d];
+            dpos[(3 * l + d) * nq + d] = 1.0;
+        }
+        /* walk up the chain: link k carries vector vk (marker offset, then the attach of the child) */
+        const double* vk = s->marker_off[l];
+        int link = k;
+        while (link >= 0) {
+            double dR[3][9];
+            cpo_drot(q + 3 + 3 * link, dR);
+            for (int j = 0; j < 3; j++) {
+                double w[3];
+                matvec3(dR[j], vk, w);
+                for (int d = 0; d < 3; d++) dpos[(3 * l + d) * nq + 3 + 3 * link + j] = w[d];
+            }
+            vk = s->attach[link];
+            link = s->parent[link];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* camera projection with optional 2x3 derivative G = d(u,v)/dp
+ * fisheye: acinoset_misc.py:1663-1679 ; pinhole-radial: acinoset_misc.py:1682-1696 */
+void cpo_project(const cpe_camera* c, const double p[3], double uv[2], double* G /*6 or NULL*/) {
+    double X[3];
+    for (int i = 0; i < 3; i++) X[i] = c->R[3 * i] * p[0] + c->R[3 * i + 1] * p[1] + c->R[3 * i + 2] * p[2] + c->t[i];
+    double a = X[0] / X[2], b = X[1] / X[2];
+    double r = sqrt(a * a + b * b);
+    double g, dg_dr; /* x_p = a*g(r), y_p = b*g(r) */
+    if (c->model == CPE_CAM_FISHEYE) {
+        double th = atan(r), t2 = th * th;
+        double thd = th * (1 + c->D[0] * t2 + c->D[1] * t2 * t2 + c->D[2] * t2 * t2 * t2 + c->D[3] * t2 * t2 * t2 * t2);
+        double dthd = 1 + 3 * c->D[0] * t2 + 5 * c->D[1] * t2 * t2 + 7 * c->D[2] * t2 * t2 * t2 + 9 * c->D[3] * t2 * t2 * t2 * t2;
+        double den = r + 1e-12;
+        g = thd / den;
+        dg_dr = (dthd / (1 + r * r) * den - thd) / (den * den);
+    } else {
+        double r2 = r * r;
+        g = 1 + c->D[0] * r2 + c->D[1] * r2 * r2 + c->D[2] * r2 * r2 * r2;
+        dg_dr = (2 * c->D[0] + 4 * c->D[1] * r2 + 6 * c->D[2] * r2 * r2) * r;
+    }
+    uv[0] = c->fx * a * g + c->cx;
+    uv[1] = c->fy * b * g + c->cy;
+    if (G) {
+        double dr_da = r > 0 ? a / r : 0, dr_db = r > 0 ? b / r : 0;
+        /* d(xp,yp)/d(a,b) */
+        double xa = g + a * dg_dr * dr_da, xb = a * dg_dr * dr_db;
+        double ya = b * dg_dr * dr_da, yb = g + b * dg_dr * dr_db;
+        /* d(a,b)/dX */
+        double iz = 1.0 / X[2];
+        double dadX[3] = {iz, 0, -a * iz}, dbdX[3] = {0, iz, -b * iz};
+        for (int k = 0; k < 3; k++) {
+            /* d(a)/dp_k = sum_i dadX[i] R[i][k] */
+            double dak = 0, dbk = 0;
+            for (int i = 0; i < 3; i++) { dak += dadX[i] * c->R[3 * i + k]; dbk += dbdX[i] * c->R[3 * i + k]; }
+            G[k] = c->fx * (xa * dak + xb * dbk);
+            G[3 + k] = c->fy * (ya * dak + yb * dbk);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* redescending loss (acinoset_misc.py:2001-2015) and its first two derivatives w.r.t. err.
+ * out[0] = rho, out[1] = d rho/d err, out[2] = d2 rho / d err2 (derivative at err==0 taken as 0) */
+static void sig3(double t, double x, double* s, double* s1, double* s2) {
+    double v = 1.0 / (1.0 + exp(-(x - t)));
+    *s = v; *s1 = v * (1 - v); *s2 = v * (1 - v) * (1 - 2 * v);
+}
+void cpo_loss(double err, double a, double b, double c, double out[3]) {
+    double e = fabs(err);
+    double sa, sa1, sa2, sb, sb1, sb2, sc, sc1, sc2;
+    sig3(a, e, &sa, &sa1, &sa2); sig3(b, e, &sb, &sb1, &sb2); sig3(c, e, &sc, &sc1, &sc2);
+    double lin = a * e - a * a / 2;
+    double cb = c - b, u = (c - e) / cb;
+    double k = a * b - a * a / 2 + (a * cb / 2) * (1 - u * u), k1 = a * (c - e) / cb, k2 = -a / cb;
+    double K = a * b - a * a / 2 + a * cb / 2;
+    double A = (1 - sa) / 2 * e * e;
+    double A1 = -sa1 / 2 * e * e + (1 - sa) * e;
+    double A2 = -sa2 / 2 * e * e - 2 * sa1 * e + (1 - sa);
+    double B = (sa - sb) * lin, B1 = (sa1 - sb1) * lin + (sa - sb) * a, B2 = (sa2 - sb2) * lin + 2 * (sa1 - sb1) * a;
+    double C = (sb - sc) * k, C1 = (sb1 - sc1) * k + (sb - sc) * k1;
+    double C2 = (sb2 - sc2) * k + 2 * (sb1 - sc1) * k1 + (sb - sc) * k2;
+    double D = sc * K, D1 = sc1 * K, D2 = sc2 * K;
+    out[0] = A + B + C + D;
+    double sgn = err > 0 ? 1.0 : (err < 0 ? -1.0 : 0.0);
+    out[1] = (A1 + B1 + C1 + D1) * sgn;
+    out[2] = A2 + B2 + C2 + D2;
+}
+
+/* curvature weight of one scalar residual in the Gauss-Newton block (PSD by construction):
+ * mode 0: max(rho''(s), rho'(|s|)/|s|, 0) -- the true curvature where the loss is convex (|s| < a),
+ *         the IRLS majoriser weight on the linear / redescending pieces;
+ * mode 1: max(rho''(s), 0) (plain Newton clipped) */
+static double curv_weight(const double L[3], double s, int mode) {
+    double c2 = L[2] > 0 ? L[2] : 0.0;
+    if (mode == 1) return c2;
+    double as = fabs(s), irls = 0.0;
+    if (as > 1e-12 && L[1] * s > 0) irls = fabs(L[1]) / as;
+    return c2 > irls ? c2 : irls;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* joint equalities (`angle_constraints` of the .robot files, cheetah.py:71-72,101,160-161).
+ * c[nc], optional dense Jacobian Cq[nc][nq]. Returns nc. */
+int cpo_constraints(const cpe_skeleton* s, const double* q, double* c, double* Cq) {
+    int nq = NQ(s), nc = 0;
+    for (int j = 0; j < s->n_joints; j++) nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
+    if (Cq) memset(Cq, 0, sizeof(double) * nc * nq);
+    int row = 0;
+    for (int j = 0; j < s->n_joints; j++) {
+        int p = s->joint_parent[j], ch = s->joint_child[j];
+        double Rp[9], Rc[9], dRp[3][9], dRc[3][9];
+        cpo_rot(q + 3 + 3 * p, Rp); cpo_rot(q + 3 + 3 * ch, Rc);
+        cpo_drot(q + 3 + 3 * p, dRp); cpo_drot(q + 3 + 3 * ch, dRc);
+        int cols[2] = {0, 2}; /* child x axis, child z axis */
+        int first = s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 0 : 1;
+        for (int t = first; t < 2; t++) {
+            int cc = cols[t];
+            double v = 0;
+            for (int i = 0; i < 3; i++) v += Rp[3 * i + 1] * Rc[3 * i + cc];
+            c[row] = v;
+            if (Cq) {
+                for (int a = 0; a < 3; a++) {
+                    double dp = 0, dc = 0;
+                    for (int i = 0; i < 3; i++) { dp += dRp[a][3 * i + 1] * Rc[3 * i + cc]; dc += Rp[3 * i + 1] * dRc[a][3 * i + cc]; }
+                    Cq[row * nq + 3 + 3 * p + a] += dp;
+                    Cq[row * nq + 3 + 3 * ch + a] += dc;
+                }
+            }
+            row++;
+        }
+    }
+    return nc;
+}
+
+/* lists of dependent / independent dofs: revolute -> child phi,psi ; hooke -> child phi */
+int cpo_split_dofs(const cpe_skeleton* s, int* indep, int* dep) {
+    int nq = NQ(s), nd = 0, ni = 0;
+    char isdep[CPE_MAX_NQ];
+    memset(isdep, 0, sizeof(isdep));
+    for (int j = 0; j < s->n_joints; j++) {
+        int ch = s->joint_child[j];
+        if (s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y) {
+            dep[nd++] = 3 + 3 * ch; dep[nd++] = 3 + 3 * ch + 2;
+            isdep[3 + 3 * ch] = isdep[3 + 3 * ch + 2] = 1;
+        } else {
+            dep[nd++] = 3 + 3 * ch; isdep[3 + 3 * ch] = 1;
+        }
+    }
+    for (int p = 0; p < nq; p++) if (!isdep[p]) indep[ni++] = p;
+    return ni;
+}
+
+/* closed-form solution of the joint equalities for the dependent angles (branch child.y = +parent.y,
+ * the one reached from the reference's initial guess phi=theta=0, psi=heading, acinoset_opt.py:574-583) */
+int cpo_project_dependents(const cpe_skeleton* s, double* q) {
+    int clamped = 0; /* 1 if a revolute child sits in the gimbal band |cos(theta)| < |a_z| (no solution) */
+    for (int j = 0; j < s->n_joints; j++) {
+        int p = s->joint_parent[j], ch = s->joint_child[j];
+        double Rp[9];
+        cpo_rot(q + 3 + 3 * p, Rp);
+        double ax = Rp[1], ay = Rp[4], az = Rp[7];
+        double* ang = q + 3 + 3 * ch;
+        double st = sin(ang[1]), ct = cos(ang[1]);
+        if (s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y) {
+            double sphi = az / ct;
+            if (sphi > 1) { sphi = 1; clamped = 1; }
+            if (sphi < -1) { sphi = -1; clamped = 1; }
+            double phi = asin(sphi), cphi = cos(phi);
+            double psi = atan2(ay, ax) - atan2(cphi, sphi * st);
+            double ref = q[3 + 3 * p + 2];
+            psi += 2 * M_PI * round((ref - psi) / (2 * M_PI));
+            ang[0] = phi; ang[2] = psi;
+        } else {
+            double sp = sin(ang[2]), cp = cos(ang[2]);
+            double num = ax * st * cp + ay * st * sp + az * ct;
+            double den = ay * cp - ax * sp;
+            ang[0] = atan2(num, den);
+        }
+    }
+    return clamped;
+}
+
+/* dense LU solve A X = B in place (n x n, nrhs); returns 0 on success */
+static int lu_solve(int n, double* A, int nrhs, double* Bm) {
+    for (int k = 0; k < n; k++) {
+        int piv = k; double mx = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; i++) if (fabs(A[i * n + k]) > mx) { mx = fabs(A[i * n + k]); piv = i; }
+        if (mx < 1e-300) return 1;
+        if (piv != k) {
+            for (int j = 0; j < n; j++) { double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+            for (int j = 0; j < nrhs; j++) { double t = Bm[k * nrhs + j]; Bm[k * nrhs + j] = Bm[piv * nrhs + j]; Bm[piv * nrhs + j] = t; }
+        }
+        for (int i = k + 1; i < n; i++) {
+            double f = A[i * n + k] / A[k * n + k];
+            if (f == 0) continue;
+            for (int j = k; j < n; j++) A[i * n + j] -= f * A[k * n + j];
+            for (int j = 0; j < nrhs; j++) Bm[i * nrhs + j] -= f * Bm[k * nrhs + j];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--)
+        for (int j = 0; j < nrhs; j++) {
+            double v = Bm[k * nrhs + j];
+            for (int i = k + 1; i < n; i++) v -= A[k * n + i] * Bm[i * nrhs + j];
+            Bm[k * nrhs + j] = v / A[k * n + k];
+        }
+    return 0;
+}
+
+/* tangent basis of the constraint manifold: Z[nq][nu], rows of independent dofs = identity, rows of
+ * dependent dofs = S = -(dc/dy)^-1 dc/du (implicit function theorem on cpo_constraints) */
+int cpo_tangent_basis(const cpe_skeleton* s, const double* q, double* Z) {
+    int nq = NQ(s), indep[CPE_MAX_NQ], dep[CPE_MAX_NQ];
+    int nu = cpo_split_dofs(s, indep, dep), nd = nq - nu;
+    double c[64], Cq[64 * CPE_MAX_NQ];
+    int nc = cpo_constraints(s, q, c, Cq);
+    if (nc != nd) return -1;
+    double* Cy = (double*)malloc(sizeof(double) * nd * nd);
+    double* Cu = (double*)malloc(sizeof(double) * nd * nu);
+    for (int r = 0; r < nd; r++) {
+        for (int k = 0; k < nd; k++) Cy[r * nd + k] = Cq[r * nq + dep[k]];
+        for (int k = 0; k < nu; k++) Cu[r * nu + k] = -Cq[r * nq + indep[k]];
+    }
+    int bad = lu_solve(nd, Cy, nu, Cu);
+    memset(Z, 0, sizeof(double) * nq * nu);
+    for (int k = 0; k < nu; k++) Z[indep[k] * nu + k] = 1.0;
+    for (int r = 0; r < nd; r++) for (int k = 0; k < nu; k++) Z[dep[r] * nu + k] = Cu[r * nu + k];
+    free(Cy); free(Cu);
+    return bad ? -2 : nu;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* acceleration slack of the constant-acceleration model for one sequence (acinoset_misc.py:639-677
+ * with the implicit-Euler collocation of make_pyomo_model, acinoset_opt.py:508; free dq0, ddq0 make the
+ * slack of frames 1 and 2 vanish -- SURVEY A.5): eps_n = (q_n - 3q_{n-1} + 3q_{n-2} - q_{n-3})/h^2 */
+void cpo_motion_eps(int nq, int N, double h, const double* q, double* eps) {
+    memset(eps, 0, sizeof(double) * N * nq);
+    for (int n = 3; n < N; n++)
+        for (int p = 0; p < nq; p++)
+            eps[n * nq + p] = (q[n * nq + p] - 3 * q[(n - 1) * nq + p] + 3 * q[(n - 2) * nq + p] - q[(n - 3) * nq + p]) / (h * h);
+}
+
+/* dq, ddq of the collocation with the gauge ddq0 = ddq1 = ddq2 of the stored solutions */
+void cpo_derivatives(int nq, int N, double h, const double* q, double* dq, double* ddq) {
+    memset(dq, 0, sizeof(double) * N * nq); memset(ddq, 0, sizeof(double) * N * nq);
+    for (int n = 1; n < N; n++) for (int p = 0; p < nq; p++) dq[n * nq + p] = (q[n * nq + p] - q[(n - 1) * nq + p]) / h;
+    for (int n = 2; n < N; n++) for (int p = 0; p < nq; p++) ddq[n * nq + p] = (dq[n * nq + p] - dq[(n - 1) * nq + p]) / h;
+    if (N >= 3) for (int p = 0; p < nq; p++) { ddq[nq + p] = ddq[2 * nq + p]; ddq[p] = ddq[2 * nq + p]; }
+    if (N >= 2) for (int p = 0; p < nq; p++) dq[p] = dq[nq + p] - h * ddq[nq + p];
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* metric-1 evaluation for one sequence: residual, dense Jacobian [C][L][2][nq], acceleration slack,
+ * per-frame robust cost (acinoset_misc.py:269-288, 459-484, 639-677) */
+void cpo_eval_resjac(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, int N,
+                     const double* q, const double* meas, const double* weight,
+                     double* r, double* Jdense, double* eps, double* cost) {
+    int nq = NQ(s), L = s->n_markers;
+    double* pos = (double*)malloc(sizeof(double) * L * 3);
+    double* dpos = (double*)malloc(sizeof(double) * L * 3 * nq);
+    for (int n = 0; n < N; n++) {
+        cpo_markers_jac(s, q + n * nq, pos, dpos);
+        double fc = 0;
+        for (int c = 0; c < C; c++)
+            for (int l = 0; l < L; l++) {
+                double uv[2], G[6];
+                cpo_project(&cams[c], pos + 3 * l, uv, G);
+                size_t base = ((size_t)(n * C + c) * L + l);
+                for (int d = 0; d < 2; d++) {
+                    double e = uv[d] - meas[base * 2 + d];
+                    if (r) r[base * 2 + d] = e;
+                    if (Jdense)
+                        for (int p = 0; p < nq; p++)
+                            Jdense[(base * 2 + d) * nq + p] = G[3 * d] * dpos[(3 * l) * nq + p] + G[3 * d + 1] * dpos[(3 * l + 1) * nq + p] + G[3 * d + 2] * dpos[(3 * l + 2) * nq + p];
+                    double Lo[3];
+                    cpo_loss(cams[c].mult * weight[base] * e, o->loss_a, o->loss_b, o->loss_c, Lo);
+                    fc += Lo[0];
+                }
+            }
+        if (cost) cost[n] = fc;
+    }
+    if (eps) cpo_motion_eps(nq, N, o->h, q, eps);
+    free(pos); free(dpos);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* relative angles x (acinoset_misc.py:508-528 numpy branch + mask :1699-1757), linear in q */
+void cpo_relative_angles(const cpe_skeleton* s, const double* q, double* x /*[nu]*/) {
+    int indep[CPE_MAX_NQ], dep[CPE_MAX_NQ];
+    int nu = cpo_split_dofs(s, indep, dep);
+    for (int k = 0; k < nu; k++) {
+        int p = indep[k];
+        x[k] = s->rel_ref[p] < 0 ? q[p] : s->rel_sign[p] * (q[p] - q[s->rel_ref[p]]);
+    }
+}
+
+/* GMM pose prior value, gradient and PSD curvature w.r.t. x22 = x[6:] (acinoset_misc.py:680-714):
+ * f = -log(sum_k w_k N(x;mu_k,Sigma_k) + 1e-12).  Hess approx = sum_k gamma_k P_k (responsibility-weighted). */
+static double gmm_eval(const cpe_priors* pr, const double* x, double* grad, double* H) {
+    int K = pr->gmm_k, D = pr->gmm_dim;
+    double lp[CPE_MAX_GMM], v[CPE_MAX_GMM][CPE_NX], mx = -1e300;
+    for (int k = 0; k < K; k++) {
+        double qf = 0;
+        for (int i = 0; i < D; i++) {
+            double a = 0;
+            for (int j = 0; j < D; j++) a += pr->gmm_P[k][i][j] * (x[j] - pr->gmm_mu[k][j]);
+            v[k][i] = a; qf += a * (x[i] - pr->gmm_mu[k][i]);
+        }
+        lp[k] = pr->gmm_logw[k] - 0.5 * qf;
+        if (lp[k] > mx) mx = lp[k];
+    }
+    double sum = 0;
+    for (int k = 0; k < K; k++) sum += exp(lp[k] - mx);
+    double S = sum * exp(mx) + 1e-12; /* mixture density + 1e-12 */
+    double f = -log(S);
+    if (grad) {
+        for (int i = 0; i < D; i++) grad[i] = 0;
+        if (H) for (int i = 0; i < D * D; i++) H[i] = 0;
+        for (int k = 0; k < K; k++) {
+            double gam = exp(lp[k]) / S;
+            for (int i = 0; i < D; i++) grad[i] += gam * v[k][i];
+            if (H) for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) H[i * D + j] += gam * pr->gmm_P[k][i][j];
+        }
+    }
+    return f;
+}
+double cpo_gmm_cost(const cpe_priors* pr, const double* x22, double* grad) { return gmm_eval(pr, x22, grad, NULL); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* per-frame terms in reduced coordinates u (independent dofs): cost, gradient g[nu], PSD block Bm[nu][nu] */
+typedef struct {
+    const cpe_skeleton* s; const cpe_camera* cams; int C; const cpe_options* o; const cpe_priors* pr;
+    int nq, nu, indep[CPE_MAX_NQ], dep[CPE_MAX_NQ], u_of_q[CPE_MAX_NQ];
+} ctx_t;
+
+static void ctx_init(ctx_t* x, const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr) {
+    x->s = s; x->cams = cams; x->C = C; x->o = o; x->pr = pr; x->nq = NQ(s);
+    x->nu = cpo_split_dofs(s, x->indep, x->dep);
+    for (int p = 0; p < x->nq; p++) x->u_of_q[p] = -1;
+    for (int k = 0; k < x->nu; k++) x->u_of_q[x->indep[k]] = k;
+}
+
+/* cost terms for one frame; returns meas cost, *cb bound-penalty cost, *cp pose-prior cost */
+static double frame_terms(const ctx_t* x, const double* qn, const double* meas, const double* weight,
+                          double* g, double* Bm, double* cb, double* cp) {
+    const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, L = s->n_markers;
+    double pos[CPE_MAX_MARKERS * 3];
+    double* dpos = NULL; double* Z = NULL; double* dpu = NULL;
+    int want = g != NULL;
+    if (want) {
+        dpos = (double*)malloc(sizeof(double) * L * 3 * nq);
+        Z = (double*)malloc(sizeof(double) * nq * nu);
+        dpu = (double*)malloc(sizeof(double) * L * 3 * nu);
+        cpo_markers_jac(s, qn, pos, dpos);
+        cpo_tangent_basis(s, qn, Z);
+        for (int i = 0; i < L * 3; i++)
+            for (int k = 0; k < nu; k++) {
+                double a = 0;
+                for (int p = 0; p < nq; p++) a += dpos[i * nq + p] * Z[p * nu + k];
+                dpu[i * nu + k] = a;
+            }
+        memset(g, 0, sizeof(double) * nu); memset(Bm, 0, sizeof(double) * nu * nu);
+    } else cpo_markers(s, qn, pos);
+    double fm = 0, rho0[3];
+    double Ju[CPE_NX + 8];
+    cpo_loss(0.0, x->o->loss_a, x->o->loss_b, x->o->loss_c, rho0);
+    for (int c = 0; c < x->C; c++)
+        for (int l = 0; l < L; l++) {
+            double w = x->cams[c].mult * weight[c * L + l];
+            if (w == 0.0) { fm += 2 * rho0[0]; continue; } /* the reference still adds rho(0) for both coordinates */
+            double uv[2], G[6];
+            cpo_project(&x->cams[c], pos + 3 * l, uv, want ? G : NULL);
+            for (int d = 0; d < 2; d++) {
+                double e = uv[d] - meas[(c * L + l) * 2 + d], sres = w * e, Lo[3];
+                cpo_loss(sres, x->o->loss_a, x->o->loss_b, x->o->loss_c, Lo);
+                fm += Lo[0];
+                if (!want) continue;
+                double gs = Lo[1] * w, cw = curv_weight(Lo, sres, x->o->curvature) * w * w;
+                for (int k = 0; k < nu; k++)
+                    Ju[k] = G[3 * d] * dpu[(3 * l) * nu + k] + G[3 * d + 1] * dpu[(3 * l + 1) * nu + k] + G[3 * d + 2] * dpu[(3 * l + 2) * nu + k];
+                for (int k = 0; k < nu; k++) {
+                    g[k] += gs * Ju[k];
+                    if (Ju[k] != 0.0) for (int m = 0; m < nu; m++) Bm[k * nu + m] += cw * Ju[k] * Ju[m];
+                }
+            }
+        }
+    /* angle bounds (cheetah.py:306-352) as a quadratic exterior penalty kappa/2 * viol^2 */
+    double fb = 0;
+    for (int b = 0; b < s->n_bounds; b++) {
+        int ia = s->bound_a[b], ib = s->bound_b[b];
+        double v = qn[ia] - (ib >= 0 ? qn[ib] : 0.0), viol = 0;
+        if (v > s->bound_up[b]) viol = v - s->bound_up[b];
+        else if (v < s->bound_lo[b]) viol = v - s->bound_lo[b];
+        if (viol == 0) continue;
+        fb += 0.5 * x->o->bound_penalty * viol * viol;
+        if (want) {
+            int ka = x->u_of_q[ia], kb = ib >= 0 ? x->u_of_q[ib] : -1;
+            double kp = x->o->bound_penalty;
+            g[ka] += kp * viol; Bm[ka * nu + ka] += kp;
+            if (kb >= 0) { g[kb] -= kp * viol; Bm[kb * nu + kb] += kp; Bm[ka * nu + kb] -= kp; Bm[kb * nu + ka] -= kp; }
+        }
+    }
+    /* GMM pose prior on x[6:] */
+    double fp = 0;
+    if (x->pr && x->pr->gmm_k > 0) {
+        double xr[CPE_NX], gr[CPE_NX], Hx[CPE_NX * CPE_NX];
+        int D = x->pr->gmm_dim, off = nu - D;
+        cpo_relative_angles(s, qn, xr);
+        fp = gmm_eval(x->pr, xr + off, want ? gr : NULL, want ? Hx : NULL);
+        if (want) {
+            /* x_k = sign_k (u_k - u_ref(k)): chain rule with the sparse +-1 map T (row k: +sign at k, -sign at ref) */
+            for (int i = 0; i < D; i++) {
+                int ki = off + i, pi = x->indep[ki];
+                double si = s->rel_ref[pi] < 0 ? 1.0 : s->rel_sign[pi];
+                int ri = s->rel_ref[pi] < 0 ? -1 : x->u_of_q[s->rel_ref[pi]];
+                g[ki] += si * gr[i]; if (ri >= 0) g[ri] -= si * gr[i];
+                for (int j = 0; j < D; j++) {
+                    int kj = off + j, pj = x->indep[kj];
+                    double sj = s->rel_ref[pj] < 0 ? 1.0 : s->rel_sign[pj];
+                    int rj = s->rel_ref[pj] < 0 ? -1 : x->u_of_q[s->rel_ref[pj]];
+                    double hv = si * sj * Hx[i * D + j];
+                    Bm[ki * nu + kj] += hv;
+                    if (rj >= 0) Bm[ki * nu + rj] -= hv;
+                    if (ri >= 0) Bm[ri * nu + kj] -= hv;
+                    if (ri >= 0 && rj >= 0) Bm[ri * nu + rj] += hv;
+                }
+            }
+        }
+    }
+    if (cb) *cb = fb; if (cp) *cp = fp;
+    if (want) { free(dpos); free(Z); free(dpu); }
+    return fm;
+}
+
+/* banded symmetric storage: A(i,j), j<=i, i-j<=kd stored at ab[i*(kd+1) + (i-j)] */
+#define AB(i, j) ab[(size_t)(i) * (kd + 1) + ((i) - (j))]
+
+static int band_cholesky(int n, int kd, double* ab) {
+    for (int j = 0; j < n; j++) {
+        double d = AB(j, j);
+        int k0 = j - kd > 0 ? j - kd : 0;
+        for (int k = k0; k < j; k++) d -= AB(j, k) * AB(j, k);
+        if (!(d > 0)) return j + 1;
+        d = sqrt(d); AB(j, j) = d;
+        int i1 = j + kd < n - 1 ? j + kd : n - 1;
+        for (int i = j + 1; i <= i1; i++) {
+            double v = AB(i, j);
+            int kk = i - kd > k0 ? i - kd : k0;
+            for (int k = kk; k < j; k++) v -= AB(i, k) * AB(j, k);
+            AB(i, j) = v / d;
+        }
+    }
+    return 0;
+}
+static void band_solve(int n, int kd, const double* ab, double* x) {
+    for (int i = 0; i < n; i++) {
+        double v = x[i];
+        int k0 = i - kd > 0 ? i - kd : 0;
+        for (int k = k0; k < i; k++) v -= AB(i, k) * x[k];
+        x[i] = v / AB(i, i);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double v = x[i];
+        int k1 = i + kd < n - 1 ? i + kd : n - 1;
+        for (int k = i + 1; k <= k1; k++) v -= AB(k, i) * x[k];
+        x[i] = v / AB(i, i);
+    }
+}
+
+/* whole-sequence evaluation in reduced coordinates. u -> q (dependents projected). Fills cost terms,
+ * and, if g != NULL, gradient g[N*nu] and band matrix ab (without damping). */
+typedef struct { double meas, model, pose, motion, bound, total; } costs_t;
+
+static void seq_eval(const ctx_t* x, int N, int kd, double* q, const double* meas, const double* weight,
+                     costs_t* ct, double* g, double* ab) {
+    const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, L = s->n_markers, C = x->C;
+    int n_tot = N * nu;
+    memset(ct, 0, sizeof(*ct));
+    double* gB = g ? (double*)malloc(sizeof(double) * (nu + nu * nu)) : NULL;
+    if (g) { memset(g, 0, sizeof(double) * n_tot); memset(ab, 0, sizeof(double) * (size_t)n_tot * (kd + 1)); }
+    int infeasible = 0;
+    for (int n = 0; n < N; n++) {
+        infeasible |= cpo_project_dependents(s, q + n * nq);
+        double cb, cp;
+        double fm = frame_terms(x, q + n * nq, meas + (size_t)n * C * L * 2, weight + (size_t)n * C * L,
+                                g ? gB : NULL, g ? gB + nu : NULL, &cb, &cp);
+        ct->meas += fm; ct->bound += cb; ct->pose += cp;
+        if (g) {
+            for (int k = 0; k < nu; k++) {
+                g[n * nu + k] += gB[k];
+                for (int m = 0; m <= k; m++) AB(n * nu + k, n * nu + m) += gB[nu + k * nu + m];
+            }
+        }
+    }
+    /* constant-acceleration model: sum_{n>=3} w_p eps_{n,p}^2 -- exact quadratic in u */
+    double ih2 = 1.0 / (x->o->h * x->o->h);
+    static const double d3[4] = {-1, 3, -3, 1}; /* coefficients of q_{n-3..n} */
+    for (int n = 3; n < N; n++)
+        for (int k = 0; k < nu; k++) {
+            int p = x->indep[k]; double w = s->motion_w[p];
+            if (w == 0) continue;
+            double e = 0;
+            for (int t = 0; t < 4; t++) e += d3[t] * q[(n - 3 + t) * nq + p];
+            e *= ih2;
+            ct->model += w * e * e;
+            if (g)
+                for (int t = 0; t < 4; t++) {
+                    int it = (n - 3 + t) * nu + k;
+                    g[it] += 2 * w * e * d3[t] * ih2;
+                    for (int t2 = 0; t2 <= t; t2++) AB(it, (n - 3 + t2) * nu + k) += 2 * w * d3[t] * d3[t2] * ih2 * ih2;
+                }
+        }
+    /* linear autoregressive motion prior on x (acinoset_misc.py:291-336): for n >= window
+     * slack = x_n - (coef.[x_{n-w};...;x_{n-1}] + b), cost sum_p lr_w[p] slack_p^2 */
+    if (x->pr && x->pr->lr_window > 0) {
+        int W = x->pr->lr_window;
+        double* xs = (double*)malloc(sizeof(double) * N * nu);
+        for (int n = 0; n < N; n++) cpo_relative_angles(s, q + n * nq, xs + n * nu);
+        /* slack_p = sum_{t=0..W} sum_j K[p][t][j] x_{n-W+t, j} - b_p ; K[.][W] = I, K[.][t<W] = -coef */
+        double* Kx = (double*)malloc(sizeof(double) * nu * (W + 1) * nu);  /* d slack_p / d x */
+        double* Ku = (double*)malloc(sizeof(double) * nu * (W + 1) * nu);  /* d slack_p / d u */
+        for (int p = 0; p < nu; p++)
+            for (int t = 0; t <= W; t++)
+                for (int j = 0; j < nu; j++)
+                    Kx[(p * (W + 1) + t) * nu + j] = t < W ? -x->pr->lr_coef[p][t * nu + j] : (p == j ? 1.0 : 0.0);
+        memset(Ku, 0, sizeof(double) * nu * (W + 1) * nu);
+        for (int p = 0; p < nu; p++)
+            for (int t = 0; t <= W; t++)
+                for (int j = 0; j < nu; j++) {
+                    int pj = x->indep[j]; double v = Kx[(p * (W + 1) + t) * nu + j];
+                    if (v == 0) continue;
+                    if (s->rel_ref[pj] < 0) Ku[(p * (W + 1) + t) * nu + j] += v;
+                    else {
+                        Ku[(p * (W + 1) + t) * nu + j] += s->rel_sign[pj] * v;
+                        Ku[(p * (W + 1) + t) * nu + x->u_of_q[s->rel_ref[pj]]] -= s->rel_sign[pj] * v;
+                    }
+                }
+        for (int n = W; n < N; n++)
+            for (int p = 0; p < nu; p++) {
+                double w = x->pr->lr_w[p];
+                if (w == 0) continue;
+                double sl = -x->pr->lr_b[p];
+                for (int t = 0; t <= W; t++) for (int j = 0; j < nu; j++) sl += Kx[(p * (W + 1) + t) * nu + j] * xs[(n - W + t) * nu + j];
+                ct->motion += w * sl * sl;
+                if (g)
+                    for (int t = 0; t <= W; t++) for (int j = 0; j < nu; j++) {
+                        double kj = Ku[(p * (W + 1) + t) * nu + j];
+                        if (kj == 0) continue;
+                        int ia = (n - W + t) * nu + j;
+                        g[ia] += 2 * w * sl * kj;
+                        for (int t2 = 0; t2 <= t; t2++) for (int j2 = 0; j2 < nu; j2++) {
+                            int ib = (n - W + t2) * nu + j2;
+                            if (ib > ia) continue;
+                            double kj2 = Ku[(p * (W + 1) + t2) * nu + j2];
+                            if (kj2 != 0) AB(ia, ib) += 2 * w * kj * kj2;
+                        }
+                    }
+            }
+        free(xs); free(Kx); free(Ku);
+    }
+    ct->total = ct->meas + ct->model + ct->pose + ct->motion + ct->bound;
+    if (infeasible) ct->total = INFINITY; /* joint equalities unsatisfiable at this u: reject the point */
+    if (gB) free(gB);
+}
+
+/* Levenberg-Marquardt over the whole trajectory in reduced coordinates (stands where IPOPT is called,
+ * acinoset_opt.py:611-617).  Same algorithm as the HIP product (DESIGN.md "Solver"). */
+cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
+                     const cpe_priors* pr, int N, const double* q_init, const double* meas,
+                     const double* weight, double* q, double* dq, double* ddq, double* positions,
+                     double* meas_err, cpe_stats* st) {
+    ctx_t x; ctx_init(&x, s, cams, C, o, pr);
+    int nq = x.nq, nu = x.nu, L = s->n_markers;
+    int bw = 3; if (pr && pr->lr_window > bw) bw = pr->lr_window;
+    int kd = (bw + 1) * nu - 1, n_tot = N * nu;
+    double* qc = (double*)malloc(sizeof(double) * N * nq);
+    double* qt = (double*)malloc(sizeof(double) * N * nq);
+    double* g = (double*)malloc(sizeof(double) * n_tot);
+    double* ab = (double*)malloc(sizeof(double) * (size_t)n_tot * (kd + 1));
+    double* abf = (double*)malloc(sizeof(double) * (size_t)n_tot * (kd + 1));
+    double* dl = (double*)malloc(sizeof(double) * n_tot);
+    memcpy(qc, q_init, sizeof(double) * N * nq);
+    costs_t cc, ctr;
+    seq_eval(&x, N, kd, qc, meas, weight, &cc, g, ab);
+    double lam = o->lambda0, nu_f = 2.0;
+    int it = 0, status = CPE_MAX_ITER;
+    if (!isfinite(cc.total)) status = CPE_NUMERICAL;
+    while (status == CPE_MAX_ITER && it < o->max_iter) {
+        it++;
+        /* (H + lam diag(H)) dl = -g */
+        memcpy(abf, ab, sizeof(double) * (size_t)n_tot * (kd + 1));
+        for (int i = 0; i < n_tot; i++) { double d = abf[(size_t)i * (kd + 1)]; abf[(size_t)i * (kd + 1)] = d + lam * (d > 1e-12 ? d : 1e-12); }
+        if (band_cholesky(n_tot, kd, abf)) { lam *= 10; if (lam > 1e12) { status = CPE_NUMERICAL; } continue; }
+        for (int i = 0; i < n_tot; i++) dl[i] = -g[i];
+        band_solve(n_tot, kd, abf, dl);
+        /* predicted reduction: -g.dl - 0.5 dl.H.dl */
+        double gd = 0, dHd = 0, maxstep = 0;
+        for (int i = 0; i < n_tot; i++) {
+            gd += g[i] * dl[i];
+            double hv = 0;
+            int k0 = i - kd > 0 ? i - kd : 0, k1 = i + kd < n_tot - 1 ? i + kd : n_tot - 1;
+            for (int k = k0; k <= i; k++) hv += ab[(size_t)i * (kd + 1) + (i - k)] * dl[k];
+            for (int k = i + 1; k <= k1; k++) hv += ab[(size_t)k * (kd + 1) + (k - i)] * dl[k];
+            dHd += dl[i] * hv;
+            if (fabs(dl[i]) > maxstep) maxstep = fabs(dl[i]);
+        }
+        double pred = -gd - 0.5 * dHd;
+        memcpy(qt, qc, sizeof(double) * N * nq);
+        for (int n = 0; n < N; n++) for (int k = 0; k < nu; k++) qt[n * nq + x.indep[k]] += dl[n * nu + k];
+        seq_eval(&x, N, kd, qt, meas, weight, &ctr, NULL, NULL);
+        double act = cc.total - ctr.total;
+        double gain = pred > 0 ? act / pred : -1;
+        if (getenv("CPO_DEBUG")) fprintf(stderr, "it %3d cost %.10f trial %.10f pred %.3e act %.3e gain %.3f lam %.2e step %.2e\n", it, cc.total, ctr.total, pred, act, gain, lam, maxstep);
+        if (isfinite(ctr.total) && act > 0 && gain > 1e-4) {
+            double rel = act / (fabs(cc.total) + 1e-30);
+            memcpy(qc, qt, sizeof(double) * N * nq);
+            seq_eval(&x, N, kd, qc, meas, weight, &cc, g, ab);
+            double f = 1 - (2 * gain - 1) * (2 * gain - 1) * (2 * gain - 1);
+            lam *= f > 1.0 / 3 ? f : 1.0 / 3; nu_f = 2.0;
+            if (lam < 1e-12) lam = 1e-12;
+            if (maxstep < o->tol_step || rel < o->tol_cost) status = CPE_OK;
+        } else {
+            lam *= nu_f; nu_f *= 2;
+            if (maxstep < o->tol_step * 1e-2) status = CPE_OK; /* step collapsed: stationary to tolerance */
+            if (lam > 1e14) status = CPE_OK;
+        }
+    }
+    /* outputs as CheetahEstimator.save writes them (acinoset_opt.py:289-361) */
+    memcpy(q, qc, sizeof(double) * N * nq);
+    if (dq && ddq) cpo_derivatives(nq, N, o->h, qc, dq, ddq);
+    double maxc = 0;
+    for (int n = 0; n < N; n++) {
+        double pos[CPE_MAX_MARKERS * 3], cv[64];
+        cpo_markers(s, qc + n * nq, pos);
+        if (positions) memcpy(positions + (size_t)n * L * 3, pos, sizeof(double) * L * 3);
+        int nc = cpo_constraints(s, qc + n * nq, cv, NULL);
+        for (int i = 0; i < nc; i++) if (fabs(cv[i]) > maxc) maxc = fabs(cv[i]);
+        if (meas_err)
+            for (int c = 0; c < C; c++) for (int l = 0; l < L; l++) {
+                double uv[2]; cpo_project(&cams[c], pos + 3 * l, uv, NULL);
+                size_t b = ((size_t)(n * C + c) * L + l) * 2;
+                meas_err[b] = uv[0] - meas[b]; meas_err[b + 1] = uv[1] - meas[b + 1];
+            }
+    }
+    if (st) {
+        st->status = status; st->iterations = it; st->lambda = lam; st->max_constraint = maxc;
+        st->cost_meas = cc.meas; st->cost_model = cc.model; st->cost_pose = cc.pose; st->cost_motion = cc.motion;
+        st->cost = o->cost_scale * (cc.meas + cc.model + cc.pose + cc.motion);
+    }
+    free(qc); free(qt); free(g); free(ab); free(abf); free(dl);
+    return status;
+}
+
+/* reduced gradient / cost at a point (used by tests to check stationarity and by finite-difference checks) */
+double cpo_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
+                     const cpe_priors* pr, int N, double* q /* dependents projected in place */,
+                     const double* meas, const double* weight, double* g /*[N*nu] or NULL*/,
+                     double* Hband /* [N*nu][kd+1] or NULL */, double* terms /*[5] or NULL*/) {
+    ctx_t x; ctx_init(&x, s, cams, C, o, pr);
+    int bw = 3; if (pr && pr->lr_window > bw) bw = pr->lr_window;
+    int kd = (bw + 1) * x.nu - 1;
+    costs_t ct;
+    double* ab = NULL;
+    if (g) ab = Hband ? Hband : (double*)malloc(sizeof(double) * (size_t)N * x.nu * (kd + 1));
+    seq_eval(&x, N, kd, q, meas, weight, &ct, g, ab);
+    if (g && !Hband) free(ab);
+    if (terms) { terms[0] = ct.meas; terms[1] = ct.model; terms[2] = ct.pose; terms[3] = ct.motion; terms[4] = ct.bound; }
+    return ct.total;
+}
+
+void cpo_default_options(cpe_options* o) {
+    o->h = 1.0 / 120; o->loss_a = 3; o->loss_b = 10; o->loss_c = 20; o->cost_scale = 1e-3;
+    o->bound_penalty = 1e6; o->lambda0 = 1e-3; o->tol_step = 1e-8; o->tol_cost = 1e-12;
+    o->max_iter = 200; o->curvature = 0;
+}
