@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload = "cfg2"): synthetic 200-frame x 6-camera x 25-marker sequences,
+phantom skeleton, fp64.  One "step" = one pass of the residual+Jacobian hot path (k_resjac) over a batch of
+B sequences resident in HBM.  `value` = frames/s of that pass over all ranks; full-trajectory solves/s
+(cpe_solve, LM + block-banded Cholesky) are timed next to it and reported in "solves".
+Sequences are independent: ranks shard them, there is no collective on the data path (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+BYTES_PER_FRAME = {25: 33360, 24: 32544}      # SURVEY 8d algorithmic bytes, C=6
+HBM_PEAK = 8.0e12
+
+
+def tile_batch(torch, d, B, dev, seed):
+    """Upload P unique sequences and tile them to B on the device (q gets a small seeded perturbation so
+    no two sequences are bit-identical)."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    P = d["q_true"].shape[0]
+    reps = (B + P - 1) // P
+    out = {}
+    for k in ("q_true", "q_init", "meas", "weight"):
+        t = torch.tensor(d[k], device=dev)
+        out[k] = t.repeat((reps,) + (1,) * (t.dim() - 1))[:B].contiguous()
+    out["q_true"] += 1e-3 * torch.randn(out["q_true"].shape, generator=g, device=dev, dtype=torch.float64)
+    out["q_init"][..., :3] += 1e-3 * torch.randn(out["q_init"][..., :3].shape, generator=g, device=dev, dtype=torch.float64)
+    return out
+
+
+def cpu_baseline(sk, cams, opts, d, budget_s=12.0):
+    """CPU oracle (oracle/, plain C, one thread) timed on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    O.lib()
+    frames, t0 = 0, time.perf_counter()
+    b = 0
+    while time.perf_counter() - t0 < budget_s and b < d["q_true"].shape[0] * 8:
+        i = b % d["q_true"].shape[0]
+        O.eval_resjac(sk, cams, opts, d["q_true"][i], d["meas"][i], d["weight"][i])
+        frames += d["q_true"].shape[1]; b += 1
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    res = O.solve(sk, cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+    ts = time.perf_counter() - t1
+    return dict(value=frames / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"{b} sequences x {d['q_true'].shape[1]} frames of the same synthetic workload, oracle/cpe_oracle.c single thread, {dt:.1f} s",
+                solves_per_s=1.0 / ts, solve_iterations=int(res["stats"].iterations), host_cores_available=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2048, help="sequences per GPU for the residual+Jacobian pass")
+    ap.add_argument("--solve-batch", type=int, default=512, help="sequences per GPU for the solve timing")
+    ap.add_argument("--markers", type=int, default=25)
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-solve", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cheetah_pose_estimation_amd import _lib, abi, skeleton, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    L, N, C = args.markers, args.frames, 6
+    sk = skeleton.build_skeleton("phantom", L)
+    cams = synth.make_cameras(C)
+    opts = abi.default_options(120.0)
+    h = _lib.Handle(sk, cams, opts, device=local)
+    S = h.S
+    P = 32
+    d = synth.make_batch(sk, cams, B=P, N=N, seed=1234 + 1000 * rank)     # sequence b uses seed 1234 + b (+ rank offset)
+    B = args.batch
+    t = tile_batch(torch, d, B, dev, seed=rank)
+    r = torch.empty((B, N, C, L, 2), dtype=torch.float64, device=dev)
+    J = torch.empty((B, N, C, S, 2), dtype=torch.float64, device=dev)
+    eps = torch.empty((B, N, sk.nq), dtype=torch.float64, device=dev)
+    stream = torch.cuda.ExternalStream(h.stream, device=dev)               # events on the stream the kernels run on
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        h.eval_resjac(t["q_true"], t["meas"], t["weight"], r, J, eps, None)
+    h.synchronize()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        h.eval_resjac(t["q_true"], t["meas"], t["weight"], r, J, eps, None)
+        ev[k][1].record(stream)
+    h.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    frames_total = world * B * N * args.steps
+    value = frames_total / elapsed
+
+    solves = None
+    if not args.no_solve:
+        Bs = args.solve_batch
+        ts_ = tile_batch(torch, d, Bs, dev, seed=100 + rank)
+        del r, J, eps
+        q = torch.empty((Bs, N, sk.nq), dtype=torch.float64, device=dev); dq = torch.empty_like(q); ddq = torch.empty_like(q)
+        pos = torch.empty((Bs, N, L, 3), dtype=torch.float64, device=dev); me = torch.empty((Bs, N, C, L, 2), dtype=torch.float64, device=dev)
+        h.solve(ts_["q_init"][:8].contiguous(), ts_["meas"][:8].contiguous(), ts_["weight"][:8].contiguous(), q[:8], dq[:8], ddq[:8], pos[:8], me[:8])   # warm-up
+        barrier()
+        t1 = time.perf_counter()
+        st, stats = h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)
+        barrier()
+        el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        its = np.array([s.iterations for s in stats])
+        stt = np.array([s.status for s in stats])
+        solves = dict(value=world * Bs / el, unit="solves/s", batch_per_gpu=Bs, seconds=el, iterations_mean=float(its.mean()),
+                      iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()))
+
+    if rank == 0:
+        bpf = BYTES_PER_FRAME.get(L, 33360)
+        ach = bpf * B * N / (kern_ms * 1e-3)
+        out = {
+            "metric": "frames/sec residual+Jacobian eval + full-traj solves/sec, 200-frame 6-cam seq",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2: synthetic 200-frame x 6-cam x 25-marker sequences, phantom skeleton, const-accel model",
+                       "frames": N, "cams": C, "markers": L, "sequences_per_gpu": B, "parallelism": f"shard{world} (independent sequences, no collective)"},
+            "solves": solves,
+            "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                         "traffic": None, "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(sk, cams, opts, d)
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+"""Loader + thin ctypes binding of libcpe.so (the HIP / C-ABI product library, include/cpe.h).
+
+There is NO CPU fallback: if the library is missing, or no MI355X is visible, every call fails loudly.
+Torch is used only as plumbing for device memory (tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpe.so")
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = None
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+
+
+class CpeError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libcpe.so (in-tree).  hipcc cross-compiles without a GPU."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)] + [os.path.join(_HERE, "..", "include", "cpe.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH,
+           os.path.join(_CSRC, "cpe_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise CpeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the solve path)")
+    lib = C.CDLL(LIB_PATH)
+    lib.cpe_last_error.restype = C.c_char_p
+    lib.cpe_stream.restype = C.c_void_p
+    lib.cpe_stream.argtypes = [C.c_void_p]
+    lib.cpe_create.argtypes = [C.POINTER(abi.Skeleton), C.POINTER(abi.Camera), C.c_int32, C.POINTER(abi.Options),
+                               C.POINTER(abi.Priors), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.cpe_destroy.argtypes = [C.c_void_p]
+    lib.cpe_synchronize.argtypes = [C.c_void_p]
+    lib.cpe_jacobian_slots.argtypes = [C.c_void_p]
+    lib.cpe_jacobian_layout.argtypes = [C.c_void_p, ip, ip]
+    lib.cpe_num_independent.argtypes = [C.c_void_p]
+    lib.cpe_independent_dofs.argtypes = [C.c_void_p, ip]
+    vp = C.c_void_p
+    lib.cpe_eval_resjac.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    lib.cpe_eval_resjac_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    lib.cpe_project_joints.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.cpe_forward_kinematics.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
+    lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
+    _LIB = lib
+    return lib
+
+
+def _check(status: int, what: str, allow=(abi.OK,)):
+    if status not in allow:
+        raise CpeError(f"{what} failed with status {status}: {load().cpe_last_error().decode()}")
+    return status
+
+
+def _ptr(t):
+    """device pointer of a torch tensor / host pointer of a numpy array / None"""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        assert t.dtype == np.float64 and t.flags["C_CONTIGUOUS"]
+        return t.ctypes.data
+    assert t.dtype.is_floating_point and t.element_size() == 8 and t.is_contiguous()
+    return t.data_ptr()
+
+
+class Handle:
+    """One solver instance = one skeleton + one camera rig + options, bound to one GPU and one HIP stream.
+    Stands where the reference builds its Pyomo model (acinoset_opt.py:459-525)."""
+
+    def __init__(self, sk: abi.Skeleton, cams, opts: abi.Options = None, priors: abi.Priors = None, device: int = 0):
+        self.lib = load()
+        self.sk, self.cams, self.n_cams = sk, cams, len(cams)
+        self.opts = opts if opts is not None else abi.default_options()
+        self._h = C.c_void_p()
+        st = self.lib.cpe_create(C.byref(sk), cams, self.n_cams, C.byref(self.opts),
+                                 C.byref(priors) if priors is not None else None, device, C.byref(self._h))
+        if st == abi.NO_DEVICE:
+            raise CpeError("no HIP device visible: the solve path has no CPU fallback (" + self.lib.cpe_last_error().decode() + ")")
+        _check(st, "cpe_create")
+        self.device = device
+        self.S = self.lib.cpe_jacobian_slots(self._h)
+        self.nu = self.lib.cpe_num_independent(self._h)
+        self.nq, self.L = sk.nq, sk.n_markers
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.cpe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return self.lib.cpe_stream(self._h)
+
+    def synchronize(self):
+        _check(self.lib.cpe_synchronize(self._h), "cpe_synchronize")
+
+    def jacobian_layout(self):
+        sm = np.empty(self.S, dtype=np.int32); sd = np.empty(self.S, dtype=np.int32)
+        _check(self.lib.cpe_jacobian_layout(self._h, sm.ctypes.data_as(ip), sd.ctypes.data_as(ip)), "cpe_jacobian_layout")
+        return sm, sd
+
+    def independent_dofs(self):
+        d = np.empty(self.nu, dtype=np.int32)
+        _check(self.lib.cpe_independent_dofs(self._h, d.ctypes.data_as(ip)), "cpe_independent_dofs")
+        return d
+
+    # ---- device-pointer entry points (torch-ROCm tensors on self.device) -------------------------------
+    def eval_resjac(self, q, meas, weight, r, J, eps, cost=None):
+        B, N = q.shape[0], q.shape[1]
+        _check(self.lib.cpe_eval_resjac(self._h, B, N, _ptr(q), _ptr(meas), _ptr(weight), _ptr(r), _ptr(J), _ptr(eps), _ptr(cost)),
+               "cpe_eval_resjac")
+
+    def project_joints(self, q):
+        return _check(self.lib.cpe_project_joints(self._h, q.shape[0], q.shape[1], _ptr(q)), "cpe_project_joints",
+                      allow=(abi.OK, abi.NUMERICAL))
+
+    def forward_kinematics(self, q, positions, com=None):
+        _check(self.lib.cpe_forward_kinematics(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(positions), _ptr(com)),
+               "cpe_forward_kinematics")
+
+    def solve(self, q_init, meas, weight, q, dq, ddq, positions, meas_err):
+        B, N = q_init.shape[0], q_init.shape[1]
+        stats = (abi.Stats * max(B, 1))()
+        st = self.lib.cpe_solve(self._h, B, N, _ptr(q_init), _ptr(meas), _ptr(weight), _ptr(q), _ptr(dq), _ptr(ddq),
+                                _ptr(positions), _ptr(meas_err), stats)
+        _check(st, "cpe_solve", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
+        return st, list(stats)[:B]
+
+    # ---- host-pointer conveniences (numpy in, numpy out; PCIe-inclusive) -------------------------------
+    def eval_resjac_host(self, q, meas, weight, want_cost=True):
+        q = np.ascontiguousarray(q, dtype=np.float64); meas = np.ascontiguousarray(meas, dtype=np.float64)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        B, N = q.shape[:2]
+        r = np.empty((B, N, self.n_cams, self.L, 2)); J = np.empty((B, N, self.n_cams, self.S, 2))
+        eps = np.empty((B, N, self.nq)); cost = np.empty((B, N)) if want_cost else None
+        _check(self.lib.cpe_eval_resjac_host(self._h, B, N, _ptr(q), _ptr(meas), _ptr(weight), _ptr(r), _ptr(J), _ptr(eps), _ptr(cost)),
+               "cpe_eval_resjac_host")
+        return r, J, eps, cost
+
+    def solve_host(self, q_init, meas, weight):
+        q_init = np.ascontiguousarray(q_init, dtype=np.float64); meas = np.ascontiguousarray(meas, dtype=np.float64)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        B, N = q_init.shape[:2]
+        q = np.empty_like(q_init); dq = np.empty_like(q_init); ddq = np.empty_like(q_init)
+        pos = np.empty((B, N, self.L, 3)); me = np.empty((B, N, self.n_cams, self.L, 2))
+        stats = (abi.Stats * max(B, 1))()
+        st = self.lib.cpe_solve_host(self._h, B, N, _ptr(q_init), _ptr(meas), _ptr(weight), _ptr(q), _ptr(dq), _ptr(ddq),
+                                     _ptr(pos), _ptr(me), stats)
+        _check(st, "cpe_solve_host", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
+        return dict(status=st, q=q, dq=dq, ddq=ddq, positions=pos, meas_err=me, stats=list(stats)[:B])

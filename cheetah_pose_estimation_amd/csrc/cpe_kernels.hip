@@ -1,0 +1,266 @@
+// cpe_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): one 64-lane wavefront per frame.
+//
+//   k_resjac        metric 1: reprojection residual + sparse Jacobian + acceleration slack per frame
+//   k_fk            marker positions + centre of mass
+//   k_project       closed-form solve of the joint equalities for the dependent angles
+//   k_frame_normal  solver: per-frame cost, reduced gradient g[28] and PSD block B[28x28]
+//   k_lm_step       solver: one Levenberg-Marquardt step per sequence (block-banded Cholesky over time)
+//   k_finalize      solver outputs (q, dq, ddq, positions, meas_err, cost terms)
+//
+// Data layout in HBM (all fp64, frame-major, so a wave's loads/stores of one frame are contiguous):
+//   q[B][N][nq]  meas[B][N][C][L][2]  weight[B][N][C][L]  r[B][N][C][L][2]  J[B][N][C][S][2]  eps[B][N][nq]
+// No MFMA: nothing here is a dense contraction larger than 28x28.
+#include <hip/hip_runtime.h>
+
+#include "cpe_device.h"
+
+// --------------------------------------------------------------------------------------------------
+// shared wave-level building blocks.  LDS arrays are private to the wave (one wave per workgroup).
+
+// sincos of all link angles of the frame held in sq -> ssc[6*link + 2*ang + {0,1}]
+__device__ __forceinline__ void wave_sincos(const DevModel* __restrict__ M, const double* sq, double* ssc, int lane) {
+    if (lane < 3 * M->nl) {
+        double s, c;
+        sincos(sq[3 + lane], &s, &c);
+        ssc[2 * lane] = s; ssc[2 * lane + 1] = c;
+    }
+}
+
+// R and dR/d(phi,theta,psi) of every link -> sR[9*(4*link + kind)]
+__device__ __forceinline__ void wave_rotations(const DevModel* __restrict__ M, const double* ssc, double* sR, int lane) {
+    for (int t = lane; t < 4 * M->nl; t += WAVE) rot_kind(ssc + 6 * (t >> 2), t & 3, sR + 9 * t);
+}
+
+// marker positions p_l = x_base + sum_k R_k v_lk  (acinoset_misc.py:1581-1659)
+__device__ __forceinline__ void wave_markers(const DevModel* __restrict__ M, const double* sq, const double* sR,
+                                             double* spos, int lane) {
+    if (lane < M->L) {
+        double p0 = sq[0], p1 = sq[1], p2 = sq[2];
+        const int n = M->chain_len[lane];
+        for (int k = 0; k < n; k++) {
+            const double* R = sR + 36 * M->chain_link[lane][k];
+            const double v0 = M->chain_vec[lane][k][0], v1 = M->chain_vec[lane][k][1], v2 = M->chain_vec[lane][k][2];
+            p0 += R[0] * v0 + R[1] * v1 + R[2] * v2;
+            p1 += R[3] * v0 + R[4] * v1 + R[5] * v2;
+            p2 += R[6] * v0 + R[7] * v1 + R[8] * v2;
+        }
+        spos[3 * lane] = p0; spos[3 * lane + 1] = p1; spos[3 * lane + 2] = p2;
+    }
+}
+
+// d p_marker / d q_dof for Jacobian slot s
+__device__ __forceinline__ void slot_dp(const DevModel* __restrict__ M, const double* sR, int s, double& d0, double& d1, double& d2) {
+    const int cpos = M->slot_cpos[s];
+    if (cpos < 0) {
+        const int ax = M->slot_dof[s];
+        d0 = ax == 0 ? 1.0 : 0.0; d1 = ax == 1 ? 1.0 : 0.0; d2 = ax == 2 ? 1.0 : 0.0;
+    } else {
+        const int l = M->slot_marker[s];
+        const double* D = sR + 9 * (4 * M->chain_link[l][cpos] + 1 + M->slot_ang[s]);
+        const double v0 = M->chain_vec[l][cpos][0], v1 = M->chain_vec[l][cpos][1], v2 = M->chain_vec[l][cpos][2];
+        d0 = D[0] * v0 + D[1] * v1 + D[2] * v2;
+        d1 = D[3] * v0 + D[4] * v1 + D[5] * v2;
+        d2 = D[6] * v0 + D[7] * v1 + D[8] * v2;
+    }
+}
+
+// closed-form solution of the joint equalities for the dependent angles (branch
+// child.y = +parent.y reached from the reference's initial guess, acinoset_opt.py:574-583).
+// Updates sq and ssc in place; returns non-zero in every lane if some revolute child sits in the gimbal
+// band |cos(theta)| < |a_z| where the equalities have no solution.
+__device__ __forceinline__ int wave_project_joints(const DevModel* __restrict__ M, double* sq, double* ssc, int lane) {
+    int clamped = 0;
+    for (int level = 0; level < 2; level++) {
+        if (lane < M->nj) {
+            const int kind = M->joint_kind[lane], p = M->joint_parent[lane], c = M->joint_child[lane];
+            const bool lvl1 = kind == CPE_JOINT_HOOKE_YZ && M->dep_of_q[3 + 3 * p] >= 0;   // parent phi is itself dependent
+            if ((level == 1) == lvl1) {
+                double a[3];
+                const double st = ssc[6 * c + 2], ct = ssc[6 * c + 3];
+                if (kind == CPE_JOINT_REVOLUTE_Y) {
+                    rot_ycol(ssc + 6 * M->joint_body[lane], a);
+                    double sphi = a[2] / ct;
+                    if (sphi > 1.0) { sphi = 1.0; clamped = 1; }
+                    if (sphi < -1.0) { sphi = -1.0; clamped = 1; }
+                    const double cphi = sqrt(fmax(0.0, 1.0 - sphi * sphi));
+                    double psi = atan2(a[1], a[0]) - atan2(cphi, sphi * st);
+                    const double ref = sq[3 + 3 * p + 2];
+                    psi += 6.283185307179586476925286766559 * rint((ref - psi) / 6.283185307179586476925286766559);
+                    sq[3 + 3 * c] = asin(sphi); sq[3 + 3 * c + 2] = psi;
+                    ssc[6 * c] = sphi; ssc[6 * c + 1] = cphi;
+                    double s, co; sincos(psi, &s, &co);
+                    ssc[6 * c + 4] = s; ssc[6 * c + 5] = co;
+                } else {
+                    rot_ycol(ssc + 6 * p, a);
+                    const double sp = ssc[6 * c + 4], cp = ssc[6 * c + 5];
+                    const double num = a[0] * st * cp + a[1] * st * sp + a[2] * ct;
+                    const double den = a[1] * cp - a[0] * sp;
+                    const double hyp = sqrt(num * num + den * den);
+                    sq[3 + 3 * c] = atan2(num, den);
+                    ssc[6 * c] = num / hyp; ssc[6 * c + 1] = den / hyp;
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+    return __any(clamped);
+}
+
+// --------------------------------------------------------------------------------------------------
+// metric 1 kernel.  One wave (= one workgroup) per frame.
+// dynamic LDS (doubles): q[nq] | sc[6 nl] | R[36 nl] | pos[3 L] | cam[23 C] | G[6 C L]
+template <bool WANT_COST>
+__global__ __launch_bounds__(WAVE) void k_resjac(const DevModel* __restrict__ M, int N,
+                                                 const double* __restrict__ q, const double* __restrict__ meas,
+                                                 const double* __restrict__ weight, double* __restrict__ r,
+                                                 double* __restrict__ J, double* __restrict__ eps,
+                                                 double* __restrict__ cost) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int nq = M->nq, nl = M->nl, L = M->L, C = M->C, S = M->S;
+    double* sq = smem;
+    double* ssc = sq + nq;
+    double* sR = ssc + 6 * nl;
+    double* spos = sR + 36 * nl;
+    double* scam = spos + 3 * L;
+    double* sG = scam + 23 * C;
+    const size_t f = blockIdx.x;
+    const double* qf = q + f * nq;
+
+    if (lane < nq) sq[lane] = qf[lane];
+    for (int t = lane; t < 23 * C; t += WAVE) scam[t] = reinterpret_cast<const double*>(M->cam)[t];
+    wave_lds_sync();
+    wave_sincos(M, sq, ssc, lane);
+    wave_lds_sync();
+    wave_rotations(M, ssc, sR, lane);
+    wave_lds_sync();
+    wave_markers(M, sq, sR, spos, lane);
+
+    // d p / d q of my Jacobian slots stay in registers (slot s = lane + 64 i)
+    double dp0[5], dp1[5], dp2[5];
+    int mk[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int s = lane + WAVE * i;
+        dp0[i] = dp1[i] = dp2[i] = 0.0; mk[i] = 0;
+        if (s < S) { mk[i] = M->slot_marker[s]; slot_dp(M, sR, s, dp0[i], dp1[i], dp2[i]); }
+    }
+    wave_lds_sync();
+
+    // project every (camera, marker) pair: residual out, d(u,v)/dp to LDS
+    const cpe_camera* cams = reinterpret_cast<const cpe_camera*>(scam);
+    const size_t pair0 = f * (size_t)(C * L);
+    double fc = 0.0;
+    for (int t = lane; t < C * L; t += WAVE) {
+        const int c = t / L, l = t - c * L;
+        double u, v, G[6];
+        project_point(cams[c], spos[3 * l], spos[3 * l + 1], spos[3 * l + 2], u, v, G);
+        const double2 z = reinterpret_cast<const double2*>(meas)[pair0 + t];
+        const double e0 = u - z.x, e1 = v - z.y;
+        reinterpret_cast<double2*>(r)[pair0 + t] = make_double2(e0, e1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) sG[6 * t + k] = G[k];
+        if (WANT_COST) {
+            const double w = cams[c].mult * weight[pair0 + t];
+            fc += robust_loss(w * e0, M->loss_a, M->loss_b, M->loss_c, 0, false).rho
+                + robust_loss(w * e1, M->loss_a, M->loss_b, M->loss_c, 0, false).rho;
+        }
+    }
+    if (WANT_COST) {
+        fc = wave_sum(fc);
+        if (lane == 0) cost[f] = fc;
+    }
+    wave_lds_sync();
+
+    // J[c][s][0..1] = G_{c,marker(s)} . dp_s : 16-byte stores, consecutive lanes -> consecutive slots
+    double2* Jf = reinterpret_cast<double2*>(J) + f * (size_t)(C * S);
+    for (int c = 0; c < C; c++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int s = lane + WAVE * i;
+            if (s < S) {
+                const double* G = sG + 6 * (c * L + mk[i]);
+                Jf[c * S + s] = make_double2(G[0] * dp0[i] + G[1] * dp1[i] + G[2] * dp2[i],
+                                             G[3] * dp0[i] + G[4] * dp1[i] + G[5] * dp2[i]);
+            }
+        }
+    }
+
+    // acceleration slack of the constant-acceleration model (free dq0/ddq0 => 0 for n < 3)
+    if (lane < nq) {
+        const int n = (int)(f % (size_t)N);
+        double e = 0.0;
+        if (n >= 3) e = (sq[lane] - 3.0 * qf[lane - nq] + 3.0 * qf[lane - 2 * nq] - qf[lane - 3 * nq]) * M->ih2;
+        eps[f * nq + lane] = e;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// forward kinematics: positions[F][L][3], com[F][3] (acinoset_misc.py:1581-1659, :722-742)
+// dynamic LDS: q[nq] | sc[6 nl] | R[36 nl] | pos[3 L]
+__global__ __launch_bounds__(WAVE) void k_fk(const DevModel* __restrict__ M, const double* __restrict__ q,
+                                             double* __restrict__ positions, double* __restrict__ com) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int nq = M->nq, nl = M->nl, L = M->L;
+    double* sq = smem;
+    double* ssc = sq + nq;
+    double* sR = ssc + 6 * nl;
+    double* spos = sR + 36 * nl;
+    const size_t f = blockIdx.x;
+    if (lane < nq) sq[lane] = q[f * nq + lane];
+    wave_lds_sync();
+    wave_sincos(M, sq, ssc, lane);
+    wave_lds_sync();
+    for (int t = lane; t < nl; t += WAVE) rot_kind(ssc + 6 * t, 0, sR + 36 * t);
+    wave_lds_sync();
+    wave_markers(M, sq, sR, spos, lane);
+    wave_lds_sync();
+    for (int t = lane; t < 3 * L; t += WAVE) positions[f * (size_t)(3 * L) + t] = spos[t];
+    if (com) {
+        // link origins by walking up the chain (depth <= CPE_MAX_CHAIN), one lane per link
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (lane < nl) {
+            const double* R = sR + 36 * lane;
+            double p0 = R[0] * M->com[lane][0] + R[1] * M->com[lane][1] + R[2] * M->com[lane][2];
+            double p1 = R[3] * M->com[lane][0] + R[4] * M->com[lane][1] + R[5] * M->com[lane][2];
+            double p2 = R[6] * M->com[lane][0] + R[7] * M->com[lane][1] + R[8] * M->com[lane][2];
+            int k = lane;
+            while (M->parent[k] >= 0) {
+                const int p = M->parent[k];
+                const double* Rp = sR + 36 * p;
+                p0 += Rp[0] * M->attach[k][0] + Rp[1] * M->attach[k][1] + Rp[2] * M->attach[k][2];
+                p1 += Rp[3] * M->attach[k][0] + Rp[4] * M->attach[k][1] + Rp[5] * M->attach[k][2];
+                p2 += Rp[6] * M->attach[k][0] + Rp[7] * M->attach[k][1] + Rp[8] * M->attach[k][2];
+                k = p;
+            }
+            const double m = M->mass[lane];
+            c0 = m * (p0 + sq[0]); c1 = m * (p1 + sq[1]); c2 = m * (p2 + sq[2]);
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+        if (lane == 0) {
+            com[3 * f] = c0 * M->inv_total_mass; com[3 * f + 1] = c1 * M->inv_total_mass; com[3 * f + 2] = c2 * M->inv_total_mass;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// dependent-angle projection in place.  dynamic LDS: q[nq] | sc[6 nl]
+__global__ __launch_bounds__(WAVE) void k_project(const DevModel* __restrict__ M, double* __restrict__ q,
+                                                  int* __restrict__ clamped_flag) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int nq = M->nq;
+    double* sq = smem;
+    double* ssc = sq + nq;
+    const size_t f = blockIdx.x;
+    if (lane < nq) sq[lane] = q[f * nq + lane];
+    wave_lds_sync();
+    wave_sincos(M, sq, ssc, lane);
+    wave_lds_sync();
+    const int cl = wave_project_joints(M, sq, ssc, lane);
+    if (lane < nq) q[f * nq + lane] = sq[lane];
+    if (cl && lane == 0 && clamped_flag) atomicOr(clamped_flag, 1);
+}
+
+#include "cpe_solver.hip.inc"

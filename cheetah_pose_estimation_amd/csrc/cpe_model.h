@@ -1,0 +1,89 @@
+// cpe_model.h -- device-side model tables (built on the host in cpe_create, read-only on the GPU).
+// gfx950 only.  All tables are derived from include/cpe.h's cpe_skeleton / cpe_camera / cpe_options.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/cpe.h"
+
+#define CPE_MAX_CHAIN 6     // links on the path root -> marker link (paw: base,bodyF,thigh,calf,hock)
+#define CPE_MAX_SLOTS 320   // structurally non-zero (marker,dof) pairs; 276 for the 25-marker cheetah
+#define CPE_MAX_MCOL 12     // reduced (independent) dofs a marker depends on
+#define CPE_MAX_TERMS 8     // terms of one reduced marker-Jacobian column (1 direct + dependent angles)
+#define CPE_MAX_DEP 32      // dependent angles (26)
+#define CPE_MAX_SCOL 8      // columns of one row of S = d(dependent)/d(independent)
+
+struct DevModel {
+    int32_t nl, L, C, nq, nu, S, nj, nb, ndep, curvature;
+    double h, ih2, loss_a, loss_b, loss_c, bound_penalty, rho0;
+
+    int32_t parent[CPE_MAX_LINKS];
+    double attach[CPE_MAX_LINKS][3];
+    double com[CPE_MAX_LINKS][3];
+    double mass[CPE_MAX_LINKS];
+    double inv_total_mass;
+
+    // marker chains: p_l = x_base + sum_k R_{chain_link[l][k]} * chain_vec[l][k]
+    int32_t chain_len[CPE_MAX_MARKERS];
+    int32_t chain_link[CPE_MAX_MARKERS][CPE_MAX_CHAIN];
+    double chain_vec[CPE_MAX_MARKERS][CPE_MAX_CHAIN][3];
+
+    // Jacobian slots (marker-major): slot -> marker, q index, chain position (-1: translation), angle
+    int32_t slot_off[CPE_MAX_MARKERS + 1];
+    int32_t slot_marker[CPE_MAX_SLOTS];
+    int32_t slot_dof[CPE_MAX_SLOTS];
+    int32_t slot_cpos[CPE_MAX_SLOTS];
+    int32_t slot_ang[CPE_MAX_SLOTS];
+
+    cpe_camera cam[CPE_MAX_CAMS];
+
+    // joints, processed parents first
+    int32_t joint_parent[CPE_MAX_JOINTS], joint_child[CPE_MAX_JOINTS], joint_kind[CPE_MAX_JOINTS];
+    int32_t joint_body[CPE_MAX_JOINTS];     // revolute: link whose y axis the whole chain shares
+    int32_t joint_dep0[CPE_MAX_JOINTS];     // first dependent row of this joint (phi; psi = +1 if revolute)
+
+    int32_t indep[CPE_NX];
+    int32_t u_of_q[CPE_MAX_NQ];             // -1 for dependent dofs
+    int32_t dep_of_q[CPE_MAX_NQ];           // -1 for independent dofs
+    double motion_w_u[CPE_NX];
+    double rel_sign_u[CPE_NX];              // x_k = rel_sign_u[k] * (u_k - u_{rel_ref_u[k]})  (rel_ref_u < 0: x_k = u_k)
+    int32_t rel_ref_u[CPE_NX];
+
+    int32_t bound_ua[CPE_MAX_BOUNDS], bound_ub[CPE_MAX_BOUNDS];
+    double bound_lo[CPE_MAX_BOUNDS], bound_up[CPE_MAX_BOUNDS];
+
+    // S rows: d(dependent angle r)/d(u_{scol[r][j]}), j < scol_n[r]
+    int32_t scol_n[CPE_MAX_DEP];
+    int32_t scol[CPE_MAX_DEP][CPE_MAX_SCOL];
+
+    // reduced marker Jacobian Dp_l[:, j] (j < mcol_n[l], reduced column mcol[l][j]) =
+    //   sum_{t < term_n} dp[term_slot] * (term_s < 0 ? 1 : Sval[term_s])     (Sval flat index = r*CPE_MAX_SCOL + j)
+    int32_t mcol_n[CPE_MAX_MARKERS];
+    int32_t mcol[CPE_MAX_MARKERS][CPE_MAX_MCOL];
+    int32_t mcol_off[CPE_MAX_MARKERS + 1];                 // prefix sum of mcol_n
+    int32_t term_n[CPE_MAX_MARKERS][CPE_MAX_MCOL];
+    int16_t term_slot[CPE_MAX_MARKERS][CPE_MAX_MCOL][CPE_MAX_TERMS];
+    int16_t term_s[CPE_MAX_MARKERS][CPE_MAX_MCOL][CPE_MAX_TERMS];
+    // flat task list over all (marker, reduced column) pairs
+    int32_t mc_total;
+    int16_t mc_marker[CPE_MAX_MARKERS * CPE_MAX_MCOL];
+    int16_t mc_j[CPE_MAX_MARKERS * CPE_MAX_MCOL];
+
+    // Hooke rows of S: entry j of row r = -(direct)/g_phi + t0 * Sval[hk_chain]
+    //   hk_kind 0: child angle hk_ang (y_p . dR_c[ang] e_z) ; 1: parent angle hk_ang (dR_p[ang] e_y . z_c) ; 2: none
+    //   hk_chain: flat Sval index of the parent's dependent-phi row entry for the same column, or -1
+    int8_t hk_kind[CPE_MAX_DEP][CPE_MAX_SCOL];
+    int8_t hk_ang[CPE_MAX_DEP][CPE_MAX_SCOL];
+    int16_t hk_chain[CPE_MAX_DEP][CPE_MAX_SCOL];
+    int32_t dep_joint[CPE_MAX_DEP];      // joint that defines dependent row r
+    int32_t dep_level[CPE_MAX_DEP];      // 0: parent fully independent (or revolute); 1: parent's phi dependent
+};
+
+// per-sequence Levenberg-Marquardt state (device global memory)
+struct SeqState {
+    int32_t cur;        // which of the two buffers holds the current iterate
+    int32_t status;     // 0 running, 1 converged, 2 numerical failure
+    int32_t iters;
+    int32_t rejects;
+    double lambda, nu, cost_cur, pred, maxstep;
+    double terms[5];    // meas, model, bound, pose, motion at the current iterate
+};
