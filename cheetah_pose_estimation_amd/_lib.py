@@ -44,6 +44,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CpeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the solve path)")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7; it must be resident before
+    # libcpe.so resolves the same soname, otherwise two runtimes fight over the device.
+    import torch  # noqa: F401
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     lib.cpe_last_error.restype = C.c_char_p
     lib.cpe_stream.restype = C.c_void_p

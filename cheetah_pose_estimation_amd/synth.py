@@ -195,7 +195,8 @@ def make_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0,
             weight[b, :, c] = wgt
         # reference initial guess (acinoset_opt.py:574-583): all angles 0, psi = heading for every link
         dx = np.diff(qt[:, 0]); dy = np.diff(qt[:, 1])
-        psi = np.arctan2(dy, dx); psi = np.pi + np.append(psi, psi[-1])   # acinoset_misc.py:450-454
+        psi = np.arctan2(dy, dx) if N > 1 else np.zeros(1)
+        psi = np.pi + (np.append(psi, psi[-1]) if N > 1 else psi)          # acinoset_misc.py:450-454
         q_init[b, :, 0:3] = qt[:, 0:3] + rng.normal(0, init_noise, (N, 3))
         for i in range(sk.n_links):
             q_init[b, :, 3 + 3 * i + 2] = psi
