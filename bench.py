@@ -46,7 +46,7 @@ def cpu_baseline(sk, cams, opts, d, budget_s=12.0):
     O.lib()
     frames, t0 = 0, time.perf_counter()
     b = 0
-    while time.perf_counter() - t0 < budget_s and b < d["q_true"].shape[0] * 8:
+    while time.perf_counter() - t0 < budget_s:
         i = b % d["q_true"].shape[0]
         O.eval_resjac(sk, cams, opts, d["q_true"][i], d["meas"][i], d["weight"][i])
         frames += d["q_true"].shape[1]; b += 1
@@ -57,6 +57,24 @@ def cpu_baseline(sk, cams, opts, d, budget_s=12.0):
     return dict(value=frames / dt, unit="frames/s", cores=1, kind="port",
                 sample=f"{b} sequences x {d['q_true'].shape[1]} frames of the same synthetic workload, oracle/cpe_oracle.c single thread, {dt:.1f} s",
                 solves_per_s=1.0 / ts, solve_iterations=int(res["stats"].iterations), host_cores_available=os.cpu_count())
+
+
+def pmc_traffic(B, N, C, L):
+    """HBM bytes per k_resjac launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_resjac.json:
+    separate FETCH_SIZE / WRITE_SIZE runs, read side doubled per MI355X_MICROARCH.md), scaled per frame.
+    None if no profile for this marker/camera count is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_resjac.json"))):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+            c = j["config"]
+            if c["C"] == C and c["L"] == L:
+                best = j["hbm_bytes_per_launch"]["total_corrected"] / (c["B"] * c["N"]) * (B * N)
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -162,7 +180,7 @@ def main():
                        "frames": N, "cams": C, "markers": L, "sequences_per_gpu": B, "parallelism": f"shard{world} (independent sequences, no collective)"},
             "solves": solves,
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                         "traffic": None, "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
+                         "traffic": pmc_traffic(B, N, C, L), "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(sk, cams, opts, d)
