@@ -68,9 +68,9 @@ class Priors(C.Structure):
 class Options(C.Structure):
     _fields_ = [
         ("h", C.c_double), ("loss_a", C.c_double), ("loss_b", C.c_double), ("loss_c", C.c_double),
-        ("cost_scale", C.c_double), ("bound_penalty", C.c_double), ("lambda0", C.c_double),
+        ("cost_scale", C.c_double), ("bound_penalty", C.c_double), ("bound_tol", C.c_double), ("lambda0", C.c_double),
         ("tol_step", C.c_double), ("tol_cost", C.c_double),
-        ("max_iter", C.c_int32), ("curvature", C.c_int32),
+        ("max_iter", C.c_int32), ("curvature", C.c_int32), ("max_outer", C.c_int32), ("_pad", C.c_int32),
     ]
 
 
@@ -79,7 +79,8 @@ class Stats(C.Structure):
         ("status", C.c_int32), ("iterations", C.c_int32),
         ("cost", C.c_double), ("cost_meas", C.c_double), ("cost_model", C.c_double),
         ("cost_pose", C.c_double), ("cost_motion", C.c_double),
-        ("lam", C.c_double), ("max_constraint", C.c_double),
+        ("lam", C.c_double), ("max_constraint", C.c_double), ("max_bound_violation", C.c_double),
+        ("outer", C.c_int32), ("_pad", C.c_int32),
     ]
 
 
@@ -89,7 +90,9 @@ def default_options(fps: float = 120.0) -> Options:
     o.h = 1.0 / fps
     o.loss_a, o.loss_b, o.loss_c = 3.0, 10.0, 20.0   # acinoset_misc.py:479-481
     o.cost_scale = 1e-3                              # acinoset_opt.py:602
-    o.bound_penalty = 1e6
+    o.bound_penalty = 1e4
+    o.bound_tol = 1e-6
+    o.max_outer = 8
     o.lambda0 = 1e-3
     o.tol_step = 1e-8
     o.tol_cost = 1e-12

@@ -27,7 +27,7 @@ struct cpe_handle {
     // solver workspace
     size_t ws_frames = 0; int ws_B = 0;
     double *qbuf = nullptr, *gbuf = nullptr, *Bbuf = nullptr, *costbuf = nullptr, *Lbuf = nullptr, *zbuf = nullptr,
-           *gtbuf = nullptr, *cmax = nullptr;
+           *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr;
     SeqState* st = nullptr;
     int* flag = nullptr;
 };
@@ -209,7 +209,8 @@ const char* cpe_last_error(void) { return g_err.c_str(); }
 
 void cpe_default_options(cpe_options* o) {
     o->h = 1.0 / 120.0; o->loss_a = 3.0; o->loss_b = 10.0; o->loss_c = 20.0; o->cost_scale = 1e-3;
-    o->bound_penalty = 1e6; o->lambda0 = 1e-3; o->tol_step = 1e-8; o->tol_cost = 1e-12; o->max_iter = 200; o->curvature = 0;
+    o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-3; o->tol_step = 1e-8; o->tol_cost = 1e-12; o->max_iter = 200;
+    o->curvature = 0; o->max_outer = 8; o->_pad = 0;
 }
 
 cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts,
@@ -233,9 +234,9 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
 }
 
 static void free_ws(cpe_handle* h) {
-    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->st};
+    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = nullptr; h->st = nullptr;
+    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = nullptr; h->st = nullptr;
     h->ws_frames = 0; h->ws_B = 0;
 }
 
@@ -317,7 +318,8 @@ static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     HIPCHK(hipMalloc(&h->qbuf, sizeof(double) * 2 * F * nq));
     HIPCHK(hipMalloc(&h->gbuf, sizeof(double) * 2 * F * nu));
     HIPCHK(hipMalloc(&h->Bbuf, sizeof(double) * 2 * F * nu * nu));
-    HIPCHK(hipMalloc(&h->costbuf, sizeof(double) * 2 * F * 4));
+    HIPCHK(hipMalloc(&h->costbuf, sizeof(double) * 2 * F * COST_STRIDE));
+    HIPCHK(hipMalloc(&h->mu, sizeof(double) * (F * (size_t)(h->hm.nb > 0 ? h->hm.nb : 1) * 2)));
     HIPCHK(hipMalloc(&h->Lbuf, sizeof(double) * F * 4 * nu * nu));
     HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * F * nu));
     HIPCHK(hipMalloc(&h->gtbuf, sizeof(double) * F * nu));
@@ -342,17 +344,20 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     const size_t Fw = F;   // buffers are laid out for exactly this call's F (strides use F)
     HIPCHK(hipMemcpyAsync(h->qbuf, q_init, sizeof(double) * F * m.nq, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
+    HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     LmParams prm;
     prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
+    prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.pad = 0;
     const size_t ldsn = lds_normal(m);
-    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf);
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu);
     hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 1, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf);
     HIPCHK(hipGetLastError());
     std::vector<SeqState> hs(B);
-    for (int it = 0; it < h->opts.max_iter; it++) {
-        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf);
+    const int rounds = h->opts.max_iter + 2 * (h->opts.max_outer > 0 ? h->opts.max_outer : 0);   // a multiplier update costs one extra round
+    for (int it = 0; it < rounds; it++) {
+        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu);
         hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 0, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf);
-        if ((it & 7) == 7 || it == h->opts.max_iter - 1) {
+        if ((it & 7) == 7 || it == rounds - 1) {
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
@@ -373,6 +378,7 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
         if (stats) {
             cpe_stats& o = stats[b];
             o.status = sb; o.iterations = S.iters; o.lambda = S.lambda; o.max_constraint = 0.0;
+            o.max_bound_violation = S.maxviol; o.outer = S.outer; o._pad = 0;
             o.cost_meas = S.terms[0]; o.cost_model = S.terms[1]; o.cost_pose = S.terms[3]; o.cost_motion = S.terms[4];
             o.cost = h->opts.cost_scale * (S.terms[0] + S.terms[1] + S.terms[3] + S.terms[4]);
         }

@@ -84,6 +84,8 @@ struct SeqState {
     int32_t status;     // 0 running, 1 converged, 2 numerical failure
     int32_t iters;
     int32_t rejects;
-    double lambda, nu, cost_cur, pred, maxstep;
+    int32_t outer;      // augmented-Lagrangian multiplier updates done
+    int32_t al_pending; // 1: the next k_frame_normal updates the multipliers at the current iterate
+    double lambda, nu, cost_cur, pred, maxstep, maxviol;
     double terms[5];    // meas, model, bound, pose, motion at the current iterate
 };

@@ -114,12 +114,15 @@ typedef struct cpe_options {
     double h;            /* 1/fps; implicit-Euler step of make_pyomo_model (acinoset_opt.py:508) */
     double loss_a, loss_b, loss_c;  /* redescending loss knots 3,10,20 (acinoset_misc.py:479-481) */
     double cost_scale;   /* 1e-3 (acinoset_opt.py:602); only scales the reported objective      */
-    double bound_penalty;/* weight of the quadratic penalty that enforces the 23 angle bounds   */
+    double bound_penalty;/* kappa of the augmented Lagrangian that enforces the 23 angle bounds   */
+    double bound_tol;    /* bounds are met when the largest violation is below this (rad)         */
     double lambda0;      /* initial Levenberg-Marquardt damping                                 */
     double tol_step;     /* converged when max |du| < tol_step                                  */
     double tol_cost;     /* ... or relative cost decrease < tol_cost                            */
     int32_t max_iter;
-    int32_t curvature;   /* 0: IRLS weight rho'(s)/s ; 1: max(rho''(s),0) + small floor         */
+    int32_t curvature;   /* 0: max(rho'', rho'(s)/s, 0) ; 1: max(rho''(s), 0)                     */
+    int32_t max_outer;   /* multiplier updates of the augmented Lagrangian (0 = pure penalty)     */
+    int32_t _pad;
 } cpe_options;
 
 typedef struct cpe_stats {
@@ -129,6 +132,9 @@ typedef struct cpe_stats {
     double cost_meas, cost_model, cost_pose, cost_motion;   /* estimator.costs (acinoset_opt.py:603-608) */
     double lambda;       /* final damping */
     double max_constraint; /* max |joint equality| at the solution */
+    double max_bound_violation; /* largest violation of an angle bound at the solution (rad) */
+    int32_t outer;       /* multiplier updates performed */
+    int32_t _pad;
 } cpe_stats;
 
 typedef struct cpe_handle cpe_handle;

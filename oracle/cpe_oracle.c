@@ -451,7 +451,7 @@ static void ctx_init(ctx_t* x, const cpe_skeleton* s, const cpe_camera* cams, in
 
 /* cost terms for one frame; returns meas cost, *cb bound-penalty cost, *cp pose-prior cost */
 static double frame_terms(const ctx_t* x, const double* qn, const double* meas, const double* weight,
-                          double* g, double* Bm, double* cb, double* cp) {
+                          const double* mu, double* g, double* Bm, double* cb, double* cp, double* viol_out) {
     const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, L = s->n_markers;
     double pos[CPE_MAX_MARKERS * 3];
     double* dpos = NULL; double* Z = NULL; double* dpu = NULL;
@@ -493,22 +493,27 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* meas, 
                 }
             }
         }
-    /* angle bounds (cheetah.py:306-352) as a quadratic exterior penalty kappa/2 * viol^2 */
-    double fb = 0;
+    /* angle bounds (cheetah.py:306-352) by an augmented Lagrangian: per bound and side a multiplier mu >= 0,
+     * psi = (max(0, mu + kappa*viol_signed)^2 - mu^2) / (2 kappa); mu == NULL means all multipliers zero */
+    double fb = 0, vmax = 0;
     for (int b = 0; b < s->n_bounds; b++) {
         int ia = s->bound_a[b], ib = s->bound_b[b];
-        double v = qn[ia] - (ib >= 0 ? qn[ib] : 0.0), viol = 0;
-        if (v > s->bound_up[b]) viol = v - s->bound_up[b];
-        else if (v < s->bound_lo[b]) viol = v - s->bound_lo[b];
-        if (viol == 0) continue;
-        fb += 0.5 * x->o->bound_penalty * viol * viol;
-        if (want) {
+        double kp = x->o->bound_penalty;
+        double v = qn[ia] - (ib >= 0 ? qn[ib] : 0.0);
+        double mu_up = mu ? mu[2 * b] : 0.0, mu_lo = mu ? mu[2 * b + 1] : 0.0;
+        double t_up = mu_up + kp * (v - s->bound_up[b]), t_lo = mu_lo + kp * (s->bound_lo[b] - v);
+        if (v - s->bound_up[b] > vmax) vmax = v - s->bound_up[b];
+        if (s->bound_lo[b] - v > vmax) vmax = s->bound_lo[b] - v;
+        double pu = t_up > 0 ? t_up : 0, pl = t_lo > 0 ? t_lo : 0;
+        fb += (pu * pu - mu_up * mu_up + pl * pl - mu_lo * mu_lo) / (2 * kp);
+        if (want && (pu > 0 || pl > 0)) {
             int ka = x->u_of_q[ia], kb = ib >= 0 ? x->u_of_q[ib] : -1;
-            double kp = x->o->bound_penalty;
-            g[ka] += kp * viol; Bm[ka * nu + ka] += kp;
-            if (kb >= 0) { g[kb] -= kp * viol; Bm[kb * nu + kb] += kp; Bm[ka * nu + kb] -= kp; Bm[kb * nu + ka] -= kp; }
+            double gv = pu - pl, hv = kp * ((pu > 0) + (pl > 0));
+            g[ka] += gv; Bm[ka * nu + ka] += hv;
+            if (kb >= 0) { g[kb] -= gv; Bm[kb * nu + kb] += hv; Bm[ka * nu + kb] -= hv; Bm[kb * nu + ka] -= hv; }
         }
     }
+    if (viol_out) *viol_out = vmax;
     /* GMM pose prior on x[6:] */
     double fp = 0;
     if (x->pr && x->pr->gmm_k > 0) {
@@ -578,10 +583,10 @@ static void band_solve(int n, int kd, const double* ab, double* x) {
 
 /* whole-sequence evaluation in reduced coordinates. u -> q (dependents projected). Fills cost terms,
  * and, if g != NULL, gradient g[N*nu] and band matrix ab (without damping). */
-typedef struct { double meas, model, pose, motion, bound, total; } costs_t;
+typedef struct { double meas, model, pose, motion, bound, total, maxviol; } costs_t;
 
 static void seq_eval(const ctx_t* x, int N, int kd, double* q, const double* meas, const double* weight,
-                     costs_t* ct, double* g, double* ab) {
+                     const double* mu /* [N][nb][2] or NULL */, costs_t* ct, double* g, double* ab) {
     const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, L = s->n_markers, C = x->C;
     int n_tot = N * nu;
     memset(ct, 0, sizeof(*ct));
@@ -590,10 +595,11 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* q, const double* mea
     int infeasible = 0;
     for (int n = 0; n < N; n++) {
         infeasible |= cpo_project_dependents(s, q + n * nq);
-        double cb, cp;
+        double cb, cp, vm;
         double fm = frame_terms(x, q + n * nq, meas + (size_t)n * C * L * 2, weight + (size_t)n * C * L,
-                                g ? gB : NULL, g ? gB + nu : NULL, &cb, &cp);
+                                mu ? mu + (size_t)n * s->n_bounds * 2 : NULL, g ? gB : NULL, g ? gB + nu : NULL, &cb, &cp, &vm);
         ct->meas += fm; ct->bound += cb; ct->pose += cp;
+        if (vm > ct->maxviol) ct->maxviol = vm;
         if (g) {
             for (int k = 0; k < nu; k++) {
                 g[n * nu + k] += gB[k];
@@ -690,12 +696,14 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     double* dl = (double*)malloc(sizeof(double) * n_tot);
     memcpy(qc, q_init, sizeof(double) * N * nq);
     costs_t cc, ctr;
-    seq_eval(&x, N, kd, qc, meas, weight, &cc, g, ab);
+    double* mu = (double*)calloc((size_t)N * s->n_bounds * 2 + 1, sizeof(double));
+    seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
     double lam = o->lambda0, nu_f = 2.0;
-    int it = 0, status = CPE_MAX_ITER;
+    int it = 0, status = CPE_MAX_ITER, outer = 0;
     if (!isfinite(cc.total)) status = CPE_NUMERICAL;
     while (status == CPE_MAX_ITER && it < o->max_iter) {
         it++;
+        int inner_done = 0;
         /* (H + lam diag(H)) dl = -g */
         memcpy(abf, ab, sizeof(double) * (size_t)n_tot * (kd + 1));
         for (int i = 0; i < n_tot; i++) { double d = abf[(size_t)i * (kd + 1)]; abf[(size_t)i * (kd + 1)] = d + lam * (d > 1e-12 ? d : 1e-12); }
@@ -716,22 +724,38 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
         double pred = -gd - 0.5 * dHd;
         memcpy(qt, qc, sizeof(double) * N * nq);
         for (int n = 0; n < N; n++) for (int k = 0; k < nu; k++) qt[n * nq + x.indep[k]] += dl[n * nu + k];
-        seq_eval(&x, N, kd, qt, meas, weight, &ctr, NULL, NULL);
+        seq_eval(&x, N, kd, qt, meas, weight, mu, &ctr, NULL, NULL);
         double act = cc.total - ctr.total;
         double gain = pred > 0 ? act / pred : -1;
-        if (getenv("CPO_DEBUG")) fprintf(stderr, "it %3d cost %.10f trial %.10f pred %.3e act %.3e gain %.3f lam %.2e step %.2e\n", it, cc.total, ctr.total, pred, act, gain, lam, maxstep);
+        if (getenv("CPO_DEBUG")) fprintf(stderr, "it %3d cost %.10f trial %.10f pred %.3e act %.3e gain %.3f lam %.2e step %.2e viol %.2e\n", it, cc.total, ctr.total, pred, act, gain, lam, maxstep, cc.maxviol);
         if (isfinite(ctr.total) && act > 0 && gain > 1e-4) {
             double rel = act / (fabs(cc.total) + 1e-30);
             memcpy(qc, qt, sizeof(double) * N * nq);
-            seq_eval(&x, N, kd, qc, meas, weight, &cc, g, ab);
+            seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
             double f = 1 - (2 * gain - 1) * (2 * gain - 1) * (2 * gain - 1);
             lam *= f > 1.0 / 3 ? f : 1.0 / 3; nu_f = 2.0;
             if (lam < 1e-12) lam = 1e-12;
-            if (maxstep < o->tol_step || rel < o->tol_cost) status = CPE_OK;
+            if (maxstep < o->tol_step || rel < o->tol_cost) inner_done = 1;
         } else {
             lam *= nu_f; nu_f *= 2;
-            if (maxstep < o->tol_step * 1e-2) status = CPE_OK; /* step collapsed: stationary to tolerance */
-            if (lam > 1e14) status = CPE_OK;
+            if (maxstep < o->tol_step * 1e-2 || lam > 1e14) inner_done = 1; /* step collapsed: stationary to tolerance */
+        }
+        if (inner_done) {
+            if (cc.maxviol > o->bound_tol && outer < o->max_outer) {
+                /* multiplier update mu <- max(0, mu + kappa * violation), then re-baseline the cost */
+                outer++;
+                for (int n = 0; n < N; n++)
+                    for (int b = 0; b < s->n_bounds; b++) {
+                        int ia = s->bound_a[b], ib = s->bound_b[b];
+                        double v = qc[n * nq + ia] - (ib >= 0 ? qc[n * nq + ib] : 0.0);
+                        double* m2 = mu + ((size_t)n * s->n_bounds + b) * 2;
+                        double t_up = m2[0] + o->bound_penalty * (v - s->bound_up[b]), t_lo = m2[1] + o->bound_penalty * (s->bound_lo[b] - v);
+                        m2[0] = t_up > 0 ? t_up : 0; m2[1] = t_lo > 0 ? t_lo : 0;
+                    }
+                seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
+                if (lam > 1e-3) lam = 1e-3;
+                nu_f = 2.0;
+            } else status = CPE_OK;
         }
     }
     /* outputs as CheetahEstimator.save writes them (acinoset_opt.py:289-361) */
@@ -753,10 +777,11 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     }
     if (st) {
         st->status = status; st->iterations = it; st->lambda = lam; st->max_constraint = maxc;
+        st->max_bound_violation = cc.maxviol; st->outer = outer;
         st->cost_meas = cc.meas; st->cost_model = cc.model; st->cost_pose = cc.pose; st->cost_motion = cc.motion;
         st->cost = o->cost_scale * (cc.meas + cc.model + cc.pose + cc.motion);
     }
-    free(qc); free(qt); free(g); free(ab); free(abf); free(dl);
+    free(qc); free(qt); free(g); free(ab); free(abf); free(dl); free(mu);
     return status;
 }
 
@@ -771,7 +796,7 @@ double cpo_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     costs_t ct;
     double* ab = NULL;
     if (g) ab = Hband ? Hband : (double*)malloc(sizeof(double) * (size_t)N * x.nu * (kd + 1));
-    seq_eval(&x, N, kd, q, meas, weight, &ct, g, ab);
+    seq_eval(&x, N, kd, q, meas, weight, NULL, &ct, g, ab);
     if (g && !Hband) free(ab);
     if (terms) { terms[0] = ct.meas; terms[1] = ct.model; terms[2] = ct.pose; terms[3] = ct.motion; terms[4] = ct.bound; }
     return ct.total;
@@ -779,6 +804,6 @@ double cpo_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const
 
 void cpo_default_options(cpe_options* o) {
     o->h = 1.0 / 120; o->loss_a = 3; o->loss_b = 10; o->loss_c = 20; o->cost_scale = 1e-3;
-    o->bound_penalty = 1e6; o->lambda0 = 1e-3; o->tol_step = 1e-8; o->tol_cost = 1e-12;
-    o->max_iter = 200; o->curvature = 0;
+    o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-3; o->tol_step = 1e-8; o->tol_cost = 1e-12;
+    o->max_iter = 200; o->curvature = 0; o->max_outer = 8;
 }

@@ -105,12 +105,13 @@ def constraints(sk, q, want_jac=False):
     return (c[:nc], Cq[:nc]) if want_jac else c[:nc]
 
 
-def project_dependents(sk, q):
+def project_dependents(sk, q, return_clamped=False):
     q = _c(q).copy()
     qf = q.reshape(-1, sk.nq)
+    clamped = np.zeros(qf.shape[0], dtype=bool)
     for i in range(qf.shape[0]):
-        lib().cpo_project_dependents(C.byref(sk), _p(qf[i]))
-    return q
+        clamped[i] = bool(lib().cpo_project_dependents(C.byref(sk), _p(qf[i])))
+    return (q, clamped.reshape(q.shape[:-1])) if return_clamped else q
 
 
 def tangent_basis(sk, q):

@@ -117,3 +117,23 @@ def test_solve_matches_oracle_within_1mm(sk25, cams6, oracle, gpu_handle_factory
         assert np.abs(out["ddq"][b] - ddq).max() < 1e-6 * max(1, np.abs(ddq).max())
         f, g, _, _, _ = oracle.objective(sk25, cams6, opts, None, out["q"][b], d["meas"][b], d["weight"][b], want_grad=True)
         assert np.abs(g).max() < 1e-2 * max(1.0, abs(f)) ** 0.5
+
+
+def test_solve_with_active_angle_bounds(sk25, cams6, oracle, gpu_handle_factory):
+    """seed 31 / N=24 ends with an ACTIVE angle bound (cheetah.py:306-352): the augmented-Lagrangian
+    multiplier updates must run on the GPU exactly as in the oracle."""
+    opts = abi.default_options()
+    h = gpu_handle_factory(sk25, cams6, opts)
+    d = synth.make_batch(sk25, cams6, B=2, N=24, seed=31)
+    out = h.solve_host(d["q_init"], d["meas"], d["weight"])
+    outers = []
+    for b in range(2):
+        ref = oracle.solve(sk25, cams6, opts, None, d["q_init"][b], d["meas"][b], d["weight"][b])
+        st = out["stats"][b]
+        assert st.status == abi.OK and ref["stats"].status == abi.OK
+        assert st.outer == ref["stats"].outer
+        outers.append(st.outer)
+        assert st.max_bound_violation < 1e-5
+        rmse = np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean())
+        assert rmse < 1e-5, rmse
+    assert max(outers) >= 1            # the instance really exercises the multiplier update

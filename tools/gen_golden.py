@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the reference's OWN pure functions (build container only).
+
+`acinoset_misc.py` imports pyomo, cv2 and the two absent git submodules at module level, none of which
+the functions below use (except `pyo.atan`).  Following SURVEY.md 8c-4, empty stand-in modules are
+pre-seeded in sys.modules (pyomo.environ.atan = math.atan) so that the module imports; then the
+reference's functions are CALLED on seeded inputs and (input, output) pairs are written to
+tests/golden/misc_golden.npz.  Only numbers are committed -- no reference source.
+
+Functions exercised (acinoset_misc.py): pt3d_to_2d_fisheye :1663, pt3d_to_2d :1682, redescending_loss
+:2001, get_uncertainty_models :1760, get_relative_angles :487 (numpy branch), get_relative_angle_mask
+:1699, get_markers :1914, get_dlc_marker_indices :1943, get_pairwise_graph :1972, rmse/traj_error :1170-1199.
+"""
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def seed_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    pyomo = mod("pyomo")
+    env = mod("pyomo.environ", atan=math.atan, ConcreteModel=_Any, Objective=_Any, Constraint=_Any, Var=_Any,
+              Param=_Any, RangeSet=_Any, value=lambda v: v)
+    pyomo.environ = env
+    util = mod("pyomo.util")
+    mod("pyomo.util.infeasible", log_infeasible_constraints=lambda *a, **k: None)
+    pyomo.util = util
+    mod("cv2")
+    shared = mod("shared")
+    pe = mod("shared.physical_education")
+    shared.physical_education = pe
+    for sub in ("system", "links", "foot", "motor", "utils", "drag", "spring", "damper"):
+        sm = mod(f"shared.physical_education.{sub}", System3D=_Any, Link3D=_Any, Foot3D=_Any, Motor3D=_Any)
+        setattr(pe, sub, sm)
+    common = mod("common")
+    pu = mod("common.py_utils")
+    common.py_utils = pu
+    pu.data_ops = mod("common.py_utils.data_ops")
+    pu.log = mod("common.py_utils.log", logger=lambda name: _Any())
+
+
+def main():
+    sys.dont_write_bytecode = True
+    seed_stubs()
+    sys.path.insert(0, REF)
+    import matplotlib
+    matplotlib.use("Agg")
+    import acinoset_misc as misc  # the reference module itself
+
+    rng = np.random.default_rng(20241008)
+    out = {}
+    # ---- projection ---------------------------------------------------------------------------------
+    n = 64
+    pts = np.c_[rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(2, 12, n)]
+    K = np.array([[1241.84, 0, 1346.96], [0, 1239.92, 773.02], [0, 0, 1.0]])
+    Df = np.array([0.0366, 0.0480, -0.0347, 0.0074])
+    Dp = np.array([-0.12, 0.05, -0.01])
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = 0.4
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + math.sin(ang) * Kx + (1 - math.cos(ang)) * Kx @ Kx
+    t = np.array([[0.3], [-0.2], [0.5]])
+    uvf = np.array([misc.pt3d_to_2d_fisheye(p[0], p[1], p[2], K, Df, R, t) for p in pts], dtype=float)
+    uvp = np.array([misc.pt3d_to_2d(p[0], p[1], p[2], K, Dp, R, t) for p in pts], dtype=float)
+    out.update(proj_pts=pts, proj_K=K, proj_Df=Df, proj_Dp=Dp, proj_R=R, proj_t=t.ravel(), proj_uv_fisheye=uvf, proj_uv_pinhole=uvp)
+    # ---- robust loss --------------------------------------------------------------------------------
+    errs = np.concatenate([np.linspace(-40, 40, 161), rng.uniform(-30, 30, 40), [0.0, 0.5, 5.0, 100.0, -100.0]])
+    out.update(loss_err=errs, loss_val=np.array([misc.redescending_loss(e, 3, 10, 20) for e in errs], dtype=float))
+    errs2 = rng.uniform(-15, 15, 32)
+    out.update(loss2_err=errs2, loss2_val=np.array([misc.redescending_loss(e, 2, 6, 9) for e in errs2], dtype=float))
+    # ---- uncertainty tables ---------------------------------------------------------------------------
+    R_pw, Q = misc.get_uncertainty_models()
+    out.update(R_pw=np.asarray(R_pw, float), Q=np.asarray(Q, float))
+    # ---- relative angles ------------------------------------------------------------------------------
+    q = rng.normal(0, 0.7, (5, 54))
+    mask = misc.get_relative_angle_mask()
+    x = np.array([np.array(sum(misc.get_relative_angles(q, fe), []))[mask] for fe in range(5)], dtype=float)
+    out.update(rel_q=q, rel_x=x, rel_mask=np.asarray(mask[0], np.int64))
+    # ---- parity metric ----------------------------------------------------------------------------------
+    a = rng.normal(size=(7, 24, 3)); b = a + rng.normal(0, 0.01, a.shape)
+    out.update(metric_a=a, metric_b=b, metric_rmse=float(misc.rmse(a, b)))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez(os.path.join(OUT, "misc_golden.npz"), **out)
+    names = dict(markers=misc.get_markers(), dlc_index=misc.get_dlc_marker_indices(), pairwise=misc.get_pairwise_graph())
+    with open(os.path.join(OUT, "misc_names.json"), "w") as f:
+        json.dump(names, f, indent=1, sort_keys=True)
+    print("wrote", os.path.join(OUT, "misc_golden.npz"), {k: np.shape(v) for k, v in out.items()})
+    print("spot:", misc.redescending_loss(0.5, 3, 10, 20), misc.redescending_loss(5, 3, 10, 20), misc.redescending_loss(100, 3, 10, 20))
+
+
+if __name__ == "__main__":
+    main()
