@@ -1,0 +1,422 @@
+"""Host-side mirror of the reference's estimator API (layer L3, acinoset_opt.py) on top of the HIP back end.
+
+Same entry points, argument meaning and return convention as the reference so that its drivers
+(`run_dataset.py:1143-1231` etc., `tests.ipynb`) call in unchanged:
+
+    est = init_trajectory(root_dir, data_path, cheetah_name, kinetic_dataset, solver_path, ...)   # acinoset_opt.py:413-430
+    ok  = estimate_kinematics(est, ...)                                                            # acinoset_opt.py:539-547
+
+and the on-disk contract is kept: `fte.pickle` (keys of acinoset_opt.py:330-361) and `cam{i}_fte.csv` in
+DeepLabCut layout (acinoset_misc.py:1346-1407).  Where the reference builds a Pyomo model and spawns IPOPT
+(acinoset_opt.py:508-525, :611-617) this module fills dense tensors and calls `cpe_solve` through the C ABI.
+Everything numerical on the solve path runs on the GPU; numpy here only moves data in and out of files.
+"""
+import json
+import os
+import pickle
+from dataclasses import dataclass, field
+from glob import glob
+from time import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib, abi, skeleton
+
+
+# ---- data classes mirroring acinoset_misc.py:40-73 ---------------------------------------------------
+@dataclass
+class TrajectoryParams:
+    data_dir: str
+    start_frame: int
+    end_frame: int
+    total_length: int
+    dlc_thresh: float
+    sync_offset: Optional[List[Dict]]
+    hand_labeled_data: bool
+    kinetic_dataset: bool
+    enable_shutter_delay_estimation: bool
+    enable_ppms: bool
+
+
+@dataclass
+class Scene:
+    scene_fpath: str
+    k_arr: np.ndarray
+    d_arr: np.ndarray
+    r_arr: np.ndarray
+    t_arr: np.ndarray
+    cam_res: Tuple[int, int]
+    fps: float
+    n_cams: int
+    cam_idx: Optional[int]
+
+
+# ---- file formats ---------------------------------------------------------------------------------------
+def load_scene(fpath: str):
+    """`*_cam_scene_sba.json` (acinoset_misc.py:1496-1516)."""
+    with open(fpath, "r", encoding="utf-8") as f:
+        data = json.load(f)
+    cams = data["cameras"]
+    arr = lambda k: np.array([c[k] for c in cams], dtype=np.float64)
+    return arr("k"), arr("d"), arr("r"), arr("t"), tuple(data["camera_resolution"])
+
+
+def find_scene_file(dir_path: str, scene_fname: Optional[str] = None):
+    """walk up from the sequence directory to `extrinsic_calib/` (acinoset_misc.py:1519-1544)."""
+    if scene_fname is None:
+        n_cams = len(glob(os.path.join(dir_path, "cam[1-9].mp4")))
+        scene_fname = f"{n_cams}_cam_scene_sba.json" if n_cams else "[1-9]_cam_scene*.json"
+    d = dir_path
+    while d and d != os.path.sep:
+        files = sorted(f for f in glob(os.path.join(d, "extrinsic_calib", scene_fname)) if "before_corrections" not in f)
+        if files:
+            k, dd, r, t, res = load_scene(files[-1])
+            return k, dd, r, t, res, int(os.path.basename(files[-1])[0]), files[-1]
+        nd = os.path.dirname(d)
+        if nd == d:
+            break
+        d = nd
+    raise FileNotFoundError(os.path.join("extrinsic_calib", scene_fname))
+
+
+def load_dlc_table(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """One DeepLabCut file -> (frame index [F], values [F, 75]) with columns (x, y, likelihood) x 25 body parts.
+    `.h5` needs PyTables (as in the reference, acinoset_misc.py:206); the `.csv` twin DeepLabCut writes beside
+    it (3 header rows: scorer / bodyparts / coords) is read without it."""
+    if path.endswith(".h5"):
+        import pandas as pd
+        df = pd.read_hdf(path)
+        return np.asarray(df.index), df.to_numpy(dtype=np.float64)
+    rows = np.genfromtxt(path, delimiter=",", skip_header=3)
+    return rows[:, 0].astype(np.int64), rows[:, 1:].astype(np.float64)
+
+
+def dlc_paths(dlc_dir: str) -> List[str]:
+    h5 = sorted(glob(os.path.join(dlc_dir, "*.h5")))
+    try:
+        import tables  # noqa: F401
+        if h5:
+            return h5
+    except Exception:
+        pass
+    csv = sorted(glob(os.path.join(dlc_dir, "*.csv")))
+    return csv if csv else h5
+
+
+def build_measurements(tables, start_frame: int, end_frame: int, sync_offset, n_cams: int, dlc_thresh: float,
+                       kinetic_dataset: bool, cam_idx: Optional[int] = None):
+    """meas[N,C,24,2] and meas_err_weight[N,C,24] exactly as `init_measurements` / `init_meas_weights` fill the
+    Pyomo params (acinoset_misc.py:211-256): row (n + start_frame - sync_offset[c]) of camera c, DLC column of
+    each marker (`get_dlc_marker_indices`), weight 1/R_pw[0][l] if likelihood > dlc_thresh else 0."""
+    off = [0] * n_cams
+    if sync_offset is not None:
+        for o in sync_offset:
+            off[o["cam"]] = o["frame"]
+    N = end_frame - start_frame
+    cams = list(range(n_cams)) if cam_idx is None else [cam_idx]
+    sigma = skeleton.measurement_sigma(24, kinetic_dataset)
+    col = np.array([skeleton.DLC_INDEX[m] for m in skeleton.MARKERS])
+    meas = np.zeros((N, len(cams), 24, 2)); weight = np.zeros((N, len(cams), 24))
+    for ci, c in enumerate(cams):
+        vals = tables[c][1]
+        rows = np.arange(N) + start_frame - off[c]
+        v = vals[rows]
+        x, y, lik = v[:, 0::3][:, col], v[:, 1::3][:, col], v[:, 2::3][:, col]
+        ok = lik > dlc_thresh
+        weight[:, ci] = np.where(ok, 1.0 / sigma[None, :], 0.0)
+        meas[:, ci, :, 0] = np.where(np.isfinite(x), x, 0.0)
+        meas[:, ci, :, 1] = np.where(np.isfinite(y), y, 0.0)
+        weight[:, ci][~(np.isfinite(x) & np.isfinite(y))] = 0.0
+    return meas, weight
+
+
+def scene_cameras(scene: Scene, kinetic_dataset: bool):
+    """abi.Camera array from the scene; multipliers [1,1,.6,.6] for the kinetic dataset (acinoset_misc.py:462-464)."""
+    idx = list(range(scene.n_cams)) if scene.cam_idx is None else [scene.cam_idx]
+    cams = (abi.Camera * len(idx))()
+    mult = [1.0, 1.0, 0.6, 0.6] if kinetic_dataset else [1.0] * 6
+    for j, c in enumerate(idx):
+        cam = cams[j]
+        cam.model = abi.CAM_PINHOLE if kinetic_dataset else abi.CAM_FISHEYE
+        K = scene.k_arr[c]
+        cam.fx, cam.fy, cam.cx, cam.cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        D = np.asarray(scene.d_arr[c]).ravel()
+        for i in range(min(4, len(D))):
+            cam.D[i] = D[i]
+        for i in range(9):
+            cam.R[i] = np.asarray(scene.r_arr[c]).reshape(-1)[i]
+        for i in range(3):
+            cam.t[i] = np.asarray(scene.t_arr[c]).reshape(-1)[i]
+        cam.mult = mult[c] if c < len(mult) else 1.0
+    return cams
+
+
+# ---- initial guess (acinoset_misc.py:381-456): host side, once per sequence ---------------------------
+def _undistort_fisheye(uv, K, D):
+    """inverse of the fisheye model of acinoset_misc.py:1663-1679 (what cv.fisheye.undistortPoints returns)"""
+    x = (uv[:, 0] - K[0, 2]) / K[0, 0]; y = (uv[:, 1] - K[1, 2]) / K[1, 1]
+    rd = np.sqrt(x * x + y * y)
+    th = rd.copy()
+    for _ in range(20):
+        t2 = th * th
+        f = th * (1 + D[0] * t2 + D[1] * t2**2 + D[2] * t2**3 + D[3] * t2**4) - rd
+        df = 1 + 3 * D[0] * t2 + 5 * D[1] * t2**2 + 7 * D[2] * t2**3 + 9 * D[3] * t2**4
+        th = th - f / df
+    s = np.where(rd > 1e-12, np.tan(th) / np.maximum(rd, 1e-12), 1.0)
+    return np.stack([x * s, y * s], axis=1)
+
+
+def _undistort_pinhole(uv, K, D):
+    x0 = (uv[:, 0] - K[0, 2]) / K[0, 0]; y0 = (uv[:, 1] - K[1, 2]) / K[1, 1]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(20):
+        r2 = x * x + y * y
+        g = 1 + D[0] * r2 + D[1] * r2**2 + D[2] * r2**3
+        x, y = x0 / g, y0 / g
+    return np.stack([x, y], axis=1)
+
+
+def _triangulate(n1, n2, R1, t1, R2, t2):
+    """linear (DLT) two-view triangulation of normalised image points, as cv.triangulatePoints"""
+    P1 = np.hstack([R1, t1.reshape(3, 1)]); P2 = np.hstack([R2, t2.reshape(3, 1)])
+    out = np.empty((len(n1), 3))
+    for i in range(len(n1)):
+        A = np.stack([n1[i, 0] * P1[2] - P1[0], n1[i, 1] * P1[2] - P1[1], n2[i, 0] * P2[2] - P2[0], n2[i, 1] * P2[2] - P2[1]])
+        X = np.linalg.svd(A)[2][-1]
+        out[i] = X[:3] / X[3]
+    return out
+
+
+def create_trajectory_estimate(tables, params: TrajectoryParams, scene: Scene, base_length: float):
+    """x, y, z, psi initial estimate from the `spine` marker (acinoset_misc.py:381-456): pairwise triangulation
+    over the camera ring (multi-view) or back-projection to 3 m depth (monocular), cubic / linear smoothing
+    spline, heading from finite differences (+pi: the skeleton's head points along -x)."""
+    from scipy.interpolate import UnivariateSpline
+    kin = params.kinetic_dataset
+    und = _undistort_pinhole if kin else _undistort_fisheye
+    col = skeleton.DLC_INDEX["spine"]
+    off = [0] * scene.n_cams
+    if params.sync_offset is not None:
+        for o in params.sync_offset:
+            off[o["cam"]] = o["frame"]
+    obs = {}
+    for c in range(scene.n_cams):
+        idx, vals = tables[c]
+        ok = vals[:, 3 * col + 2] > params.dlc_thresh
+        obs[c] = {int(f) + off[c]: vals[i, 3 * col:3 * col + 2] for i, f in enumerate(idx) if ok[i]}
+    pts = {}
+    if scene.cam_idx is None:
+        ncam = 2 if kin else scene.n_cams                       # kinetic dataset: near-side cameras only (:399-401)
+        pairs = [(i % ncam, (i + 1) % ncam) for i in range(ncam)]
+        for a, b in pairs:
+            common = sorted(set(obs[a]) & set(obs[b]))
+            if not common:
+                continue
+            ua = np.array([obs[a][f] for f in common], dtype=np.float32).astype(np.float64)
+            ub = np.array([obs[b][f] for f in common], dtype=np.float32).astype(np.float64)
+            X = _triangulate(und(ua, scene.k_arr[a], scene.d_arr[a]), und(ub, scene.k_arr[b], scene.d_arr[b]),
+                             scene.r_arr[a], scene.t_arr[a].ravel(), scene.r_arr[b], scene.t_arr[b].ravel())
+            for f, x in zip(common, X):
+                pts.setdefault(f, []).append(x)
+        frames = np.array(sorted(pts))
+        xyz = np.array([np.mean(pts[f], axis=0) for f in frames])
+    else:
+        c = scene.cam_idx
+        frames = np.array(sorted(obs[c]))
+        uv = np.array([obs[c][f] for f in frames], dtype=np.float32).astype(np.float64)
+        nrm = und(uv, scene.k_arr[c], scene.d_arr[c])
+        Xc = 3.0 * np.c_[nrm, np.ones(len(nrm))]
+        R, t = scene.r_arr[c], scene.t_arr[c].ravel()
+        xyz = (Xc - t) @ R                                           # R^T (Xc - t)
+    xyz = xyz.copy()
+    xyz[:, 0] += base_length / 2.0                                   # :424
+    k = 1 if kin else 3
+    fr = np.arange(params.end_frame)
+    est = [np.asarray(UnivariateSpline(frames, xyz[:, d], k=k)(fr)) for d in range(3)]
+    psi = np.arctan2(np.diff(est[1]) * scene.fps, np.diff(est[0]) * scene.fps)
+    psi = np.pi + np.append(psi, psi[-1])
+    return est[0], est[1], est[2], psi
+
+
+# ---- estimator object ---------------------------------------------------------------------------------------
+@dataclass
+class CheetahEstimator:
+    """Counterpart of acinoset_opt.CheetahEstimator (acinoset_opt.py:21-70): holds the problem tensors instead
+    of a Pyomo model."""
+    name: str
+    data_path: str
+    params: TrajectoryParams
+    scene: Scene
+    skeleton: abi.Skeleton
+    cams: object
+    meas: np.ndarray                 # [N, C, 24, 2]
+    weight: np.ndarray               # [N, C, 24]
+    scale_forces_by: float
+    kinematic_model: bool
+    tables: object = None
+    device: int = 0
+    opt_time_s: float = 0.0
+    costs: Dict[str, float] = field(default_factory=dict)
+    result: Optional[dict] = None
+    com_pos: Optional[np.ndarray] = None
+    com_vel: Optional[np.ndarray] = None
+
+    def get_objective_cost(self) -> float:
+        return float(self.result["stats"][0].cost) if self.result else float("nan")
+
+    def relative_angles(self, q: np.ndarray) -> np.ndarray:
+        """x (28) of acinoset_misc.py:508-528 + mask :1699-1757, linear in q"""
+        sk = self.skeleton
+        ind = skeleton.independent_dofs(sk)
+        ref = np.array(sk.rel_ref[:sk.nq]); sgn = np.array(sk.rel_sign[:sk.nq])
+        rel = np.where(ref < 0, q, sgn * (q - q[..., np.maximum(ref, 0)]))
+        return rel[..., ind]
+
+    def save(self, out_dir: str, fname: str = "fte", out_dir_prefix: Optional[str] = None):
+        """fte.pickle + cam*_fte.csv, acinoset_opt.py:278-373."""
+        res, params, scene = self.result, self.params, self.scene
+        if out_dir_prefix:
+            out_dir = os.path.join(out_dir_prefix, self.data_path, out_dir or "fte")
+        else:
+            out_dir = os.path.join(params.data_dir, out_dir or "fte")
+        os.makedirs(out_dir, exist_ok=True)
+        q, dq, ddq = res["q"][0], res["dq"][0], res["ddq"][0]
+        output = dict(positions=res["positions"][0], x=self.relative_angles(q), dx=self.relative_angles(dq),
+                      ddx=self.relative_angles(ddq), q=q, dq=dq, ddq=ddq, com_pos=self.com_pos, com_vel=self.com_vel,
+                      tau={}, meas_err=res["meas_err"][0][..., None], obj_cost=self.get_objective_cost(),
+                      processing_time_s=self.opt_time_s, start_frame=params.start_frame)
+        with open(os.path.join(out_dir, f"{fname}.pickle"), "wb") as f:
+            pickle.dump(output, f)
+        off = [0] * scene.n_cams
+        if params.sync_offset is not None:
+            for o in params.sync_offset:
+                off[o["cam"]] = o["frame"]
+        all_cams = scene_cameras(Scene(scene.scene_fpath, scene.k_arr, scene.d_arr, scene.r_arr, scene.t_arr, scene.cam_res,
+                                       scene.fps, scene.n_cams, None), params.kinetic_dataset)
+        from .synth import project_numpy
+        pos = res["positions"][0]
+        for i in range(scene.n_cams):
+            uv, _ = project_numpy(all_cams[i], pos)
+            bad = (uv > np.array(scene.cam_res)) | (uv < 0)
+            uv[bad.any(-1)] = np.nan                                # acinoset_misc.py:1385-1386
+            n_frames = pos.shape[0]
+            path = os.path.join(out_dir, f"cam{i + 1}_{fname}.csv")
+            with open(path, "w") as f:                              # DLC MultiIndex layout (:1373-1399)
+                f.write("bodyparts," + ",".join(f"{m},{m},{m}" for m in skeleton.MARKERS) + "\n")
+                f.write("coords," + ",".join("x,y,likelihood" for _ in skeleton.MARKERS) + "\n")
+                for n in range(n_frames):
+                    row = ",".join((("" if np.isnan(uv[n, l, 0]) else repr(float(uv[n, l, 0]))) + "," +
+                                    ("" if np.isnan(uv[n, l, 1]) else repr(float(uv[n, l, 1]))) + ",") for l in range(24))
+                    f.write(f"{params.start_frame - off[i] + n},{row}\n")
+        return out_dir
+
+
+def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_dataset: bool, solver_path: Optional[str] = None,
+                    start_frame: int = -1, end_frame: int = -1, dlc_thresh: float = 0.5,
+                    include_camera_constraints: bool = True, enable_eom_slack: bool = True, kinematic_model: bool = False,
+                    monocular_enable: bool = False, override_monocular_cam: Optional[int] = None,
+                    disable_contact_lcp: bool = True, bound_eom_error: Optional[Tuple[float, float]] = None,
+                    shutter_delay_estimation: bool = False, enable_ppm: bool = False, hand_labeled_data: bool = False,
+                    device: int = 0) -> CheetahEstimator:
+    """Same signature and meaning as acinoset_opt.init_trajectory (acinoset_opt.py:413-536).  `solver_path`
+    (the IPOPT binary of the reference) is accepted and ignored."""
+    if not kinematic_model:
+        raise NotImplementedError("the dynamic (kinetic) model -- SURVEY 8 rows a12/a13 -- is not built yet; pass kinematic_model=True")
+    if shutter_delay_estimation or enable_ppm or hand_labeled_data:
+        raise NotImplementedError("shutter delay / pairwise pseudo-measurements / hand labels are SURVEY 8f-4 (next)")
+    if cheetah_name not in ("jules", "phantom", "shiraz", "arabia"):
+        cheetah_name = "acinoset"                                   # acinoset_opt.py:455-456
+    model_name = f"{cheetah_name}-02" if kinetic_dataset else cheetah_name
+    data_dir = os.path.join(root_dir, data_path)
+    cam_idx, sync_offset = None, None
+    if start_frame < 0 or end_frame < 0:
+        with open(os.path.join(data_dir, "metadata.json"), "r", encoding="utf-8") as f:
+            md = json.load(f)
+        start_frame, end_frame, sync_offset = md["start_frame"], md["end_frame"], md["cam_sync"]
+        cam_idx = md["monocular_cam"] if monocular_enable else None
+        cam_idx = cam_idx if override_monocular_cam is None else override_monocular_cam
+    total_length = end_frame - start_frame
+    dlc_dir = os.path.join(data_dir, "dlc")
+    assert os.path.exists(dlc_dir), dlc_dir
+    k_arr, d_arr, r_arr, t_arr, cam_res, n_cams, scene_fpath = find_scene_file(data_dir)
+    fps = 200.0
+    if not kinetic_dataset and "2019" in data_path:
+        fps = 120.0
+    elif not kinetic_dataset and "2017" in data_path:
+        fps = 90.0                                                   # acinoset_opt.py:483-487
+    d_arr = d_arr.reshape((n_cams, -1))
+    params = TrajectoryParams(data_dir, start_frame, end_frame, total_length, dlc_thresh, sync_offset, hand_labeled_data,
+                              kinetic_dataset, shutter_delay_estimation, enable_ppm)
+    scene = Scene(scene_fpath, k_arr, d_arr, r_arr, t_arr, cam_res, fps, n_cams, cam_idx)
+    paths = dlc_paths(dlc_dir)
+    assert n_cams == len(paths), f"# of dlc files != # of cams in {scene_fpath}"
+    tables = [load_dlc_table(p) for p in paths]
+    sk = skeleton.build_skeleton(model_name, 24, kinetic_dataset)
+    meas, weight = build_measurements(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx)
+    total_mass = sum(sk.mass[i] for i in range(sk.n_links))
+    return CheetahEstimator(cheetah_name, data_path, params, scene, sk, scene_cameras(scene, kinetic_dataset), meas, weight,
+                            total_mass * 9.81, kinematic_model, tables, device)
+
+
+def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True, monocular_constraints: bool = False,
+                        disable_pose_prior: bool = False, disable_motion_prior: bool = False,
+                        pose_model_num_components: int = 5, motion_model_window_size: int = 4,
+                        motion_model_sparse_solution: bool = True, out_dir_prefix: Optional[str] = None,
+                        q_init: Optional[np.ndarray] = None, options: Optional[abi.Options] = None) -> bool:
+    """Same signature as acinoset_opt.estimate_kinematics (acinoset_opt.py:539-547) plus two optional
+    keyword arguments.  Returns True when the solve converged (IPOPT `ok`+`optimal` in the reference)."""
+    est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
+    if monocular_constraints and scene.cam_idx is not None and not (disable_pose_prior and disable_motion_prior):
+        raise NotImplementedError("learned pose / motion priors on the GPU are SURVEY 8 rows a10/a11 (next); "
+                                  "pass disable_pose_prior=True, disable_motion_prior=True")
+    N = params.end_frame - params.start_frame
+    if q_init is None:
+        base_len = 2.0 * abs(sk.marker_off[5][0])
+        x, y, z, psi = create_trajectory_estimate(est.tables, params, scene, base_len)
+        q_init = np.zeros((N, sk.nq))                               # acinoset_opt.py:574-583
+        sl = slice(params.start_frame, params.start_frame + N)
+        q_init[:, 0], q_init[:, 1], q_init[:, 2] = x[sl], y[sl], z[sl]
+        for i in range(sk.n_links):
+            q_init[:, 3 + 3 * i + 2] = psi[sl]
+    opts = options if options is not None else abi.default_options(scene.fps)
+    opts.h = 1.0 / scene.fps
+    h = _lib.Handle(sk, est.cams, opts, device=est.device)
+    try:
+        t0 = time()
+        res = h.solve_host(q_init[None], est.meas[None], est.weight[None])
+        est.opt_time_s = time() - t0
+        import torch
+        dev = torch.device("cuda", est.device)
+        qd = torch.tensor(res["q"], device=dev)
+        pos = torch.empty((1, N, 24, 3), dtype=torch.float64, device=dev); com = torch.empty((1, N, 3), dtype=torch.float64, device=dev)
+        h.forward_kinematics(qd, pos, com); h.synchronize()
+        est.com_pos = com[0].cpu().numpy()
+        est.com_vel = (est.com_pos[1:] - est.com_pos[:-1]) * scene.fps     # acinoset_misc.py:742
+    finally:
+        h.close()
+    st = res["stats"][0]
+    est.result = res
+    est.costs = {"measurement": st.cost_meas, "model": st.cost_model, "pose": st.cost_pose, "motion": st.cost_motion}
+    if solver_output:
+        print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- model: {st.cost_model}\n"
+              f"status {st.status}, {st.iterations} LM iterations, {est.opt_time_s:.3f} s")
+    ok = st.status == abi.OK
+    if ok:
+        fname = "fte_kinematic"
+        fname = fname if scene.cam_idx is None or monocular_constraints else "fte_kinematic_orig"
+        fname = fname if scene.cam_idx is None else f"{fname}_{scene.cam_idx}"    # acinoset_opt.py:626-628
+        est.save(fname, out_dir_prefix=out_dir_prefix)
+    return ok
+
+
+def determine_contacts(estimator, monocular: bool = False, verbose: bool = False):
+    raise NotImplementedError("contact detection (acinoset_opt.py:638-690) is a CPU pre-step outside the hot path (SURVEY 8f-2)")
+
+
+def estimate_kinetics(estimator, *args, **kwargs) -> bool:
+    raise NotImplementedError("physics-based model (acinoset_opt.py:693-963): SURVEY 8 row a12, not built yet")
+
+
+def estimate_grf(estimator, *args, **kwargs) -> bool:
+    raise NotImplementedError("per-frame GRF fit (acinoset_opt.py:966-1048): SURVEY 8 row a13, not built yet")

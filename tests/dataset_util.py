@@ -1,0 +1,52 @@
+"""Writes a synthetic AcinoSet-style directory tree (metadata.json, dlc/cam*.csv in DeepLabCut layout,
+extrinsic_calib/N_cam_scene_sba.json) so the estimator API can be driven through FILES as the reference is."""
+import json
+import os
+
+import numpy as np
+
+from cheetah_pose_estimation_amd import skeleton, synth
+
+
+def write_dataset(root, data_path="2019_03_07/synth/run", N=30, pad=4, seed=5, n_cams=6, noise_px=1.0):
+    sk = skeleton.build_skeleton("phantom", 24)
+    cams = synth.make_cameras(n_cams)
+    rng = np.random.default_rng(seed)
+    total = N + 2 * pad
+    qt = synth.truth_trajectory(sk, total, 120.0, rng)
+    qt[:, 0] += 6.0                                       # mid-track: every camera sees the animal
+    pos, _ = synth.fk_numpy(sk, qt)
+    ddir = os.path.join(root, data_path)
+    os.makedirs(os.path.join(ddir, "dlc"), exist_ok=True)
+    os.makedirs(os.path.join(root, data_path.split("/")[0], "extrinsic_calib"), exist_ok=True)
+    names = [None] * 25
+    for m, i in skeleton.DLC_INDEX.items():
+        names[i] = m
+    names[21] = "unused"
+    liks = []
+    for c in range(n_cams):
+        uv, z = synth.project_numpy(cams[c], pos)
+        uv = uv + rng.normal(0, noise_px, uv.shape)
+        lik = rng.uniform(0.55, 1.0, (total, 24))
+        lik[rng.random((total, 24)) < 0.15] = 0.2          # low-likelihood drop-outs
+        vals = np.zeros((total, 75))
+        for l, m in enumerate(skeleton.MARKERS):
+            j = skeleton.DLC_INDEX[m]
+            vals[:, 3 * j], vals[:, 3 * j + 1], vals[:, 3 * j + 2] = uv[:, l, 0], uv[:, l, 1], lik[:, l]
+        with open(os.path.join(ddir, "dlc", f"cam{c + 1}DLC.csv"), "w") as f:
+            f.write("scorer," + ",".join(["DLC"] * 75) + "\n")
+            f.write("bodyparts," + ",".join(f"{n},{n},{n}" for n in names) + "\n")
+            f.write("coords," + ",".join(["x,y,likelihood"] * 25) + "\n")
+            for n in range(total):
+                f.write(f"{n}," + ",".join(repr(float(v)) for v in vals[n]) + "\n")
+        liks.append(lik)
+    scene = {"camera_resolution": [synth.IMG_W, synth.IMG_H], "cameras": []}
+    for c in range(n_cams):
+        cam = cams[c]
+        scene["cameras"].append({"k": [[cam.fx, 0, cam.cx], [0, cam.fy, cam.cy], [0, 0, 1]], "d": [[cam.D[i]] for i in range(4)],
+                                 "r": np.array(cam.R[:]).reshape(3, 3).tolist(), "t": [[cam.t[i]] for i in range(3)]})
+    with open(os.path.join(root, data_path.split("/")[0], "extrinsic_calib", f"{n_cams}_cam_scene_sba.json"), "w") as f:
+        json.dump(scene, f)
+    with open(os.path.join(ddir, "metadata.json"), "w") as f:
+        json.dump({"start_frame": pad, "end_frame": pad + N, "cam_sync": [], "ground_plane_height": 0.0, "monocular_cam": 2}, f)
+    return dict(sk=sk, cams=cams, q_true=qt, pos_true=pos, start=pad, N=N, data_path=data_path, lik=liks)

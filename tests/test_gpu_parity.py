@@ -137,3 +137,34 @@ def test_solve_with_active_angle_bounds(sk25, cams6, oracle, gpu_handle_factory)
         rmse = np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean())
         assert rmse < 1e-5, rmse
     assert max(outers) >= 1            # the instance really exercises the multiplier update
+
+
+def test_estimator_api_end_to_end_from_files(tmp_path, oracle):
+    """The reference's call sequence (tests.ipynb cells 1-2; run_dataset.py:1160-1190) through FILES:
+    init_trajectory -> estimate_kinematics -> fte.pickle + cam*_fte.csv in the AcinoSet layout."""
+    import os
+    import pickle
+    from cheetah_pose_estimation_amd import estimator as E
+    from dataset_util import write_dataset
+    info = write_dataset(str(tmp_path), N=30)
+    est = E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, solver_path="/unused/ipopt", kinematic_model=True)
+    assert est.scene.fps == 120.0 and est.meas.shape == (30, 6, 24, 2)
+    assert E.estimate_kinematics(est, solver_output=False) is True
+    out_dir = os.path.join(str(tmp_path), info["data_path"], "fte_kinematic")
+    with open(os.path.join(out_dir, "fte.pickle"), "rb") as f:      # our own file: plain pickle of numpy arrays
+        d = pickle.load(f)
+    for k, shp in (("positions", (30, 24, 3)), ("x", (30, 28)), ("dx", (30, 28)), ("ddx", (30, 28)), ("q", (30, 54)), ("dq", (30, 54)),
+                   ("ddq", (30, 54)), ("com_pos", (30, 3)), ("com_vel", (29, 3)), ("meas_err", (30, 6, 24, 2, 1))):
+        assert d[k].shape == shp, k
+    assert d["start_frame"] == 4 and d["tau"] == {} and d["processing_time_s"] > 0 and np.isfinite(d["obj_cost"])
+    truth = info["pos_true"][4:34]
+    assert np.sqrt(((d["positions"] - truth) ** 2).sum(-1).mean()) < 0.03        # 1 px noise, 6 views -> cm level
+    assert np.abs(d["com_pos"] - oracle.com(est.skeleton, d["q"])).max() < 1e-12
+    assert np.abs(d["positions"] - oracle.markers(est.skeleton, d["q"])).max() < 1e-12
+    rows = np.genfromtxt(os.path.join(out_dir, "cam1_fte.csv"), delimiter=",", skip_header=2)
+    assert rows.shape == (30, 1 + 72) and rows[0, 0] == 4
+    cam = info["cams"][0]
+    uv, _ = synth.project_numpy(cam, d["positions"])
+    got = rows[:, 1:].reshape(30, 24, 3)[:, :, :2]
+    ok = np.isfinite(got)
+    assert np.abs(got[ok] - uv[ok]).max() < 1e-9
