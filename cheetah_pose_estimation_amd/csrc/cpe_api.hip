@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@ static cpe_status fail(cpe_status s, const std::string& m) { g_err = m; return s
 
 struct cpe_handle {
     int device = 0;
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     DevModel hm;                 // host copy
     DevModel* dm = nullptr;      // device copy
@@ -197,7 +199,6 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
     return CPE_OK;
 }
 
-static size_t lds_resjac(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C + 6 * m.C * m.L); }
 static size_t lds_fk(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C); }
 static size_t lds_normal(const DevModel& m) {
     return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C + 3 * m.S + CPE_MAX_SCOL * m.ndep + 9 * m.L + 3 * m.mc_total + m.nu * m.nu + m.nu);
@@ -225,6 +226,16 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
     cpe_status s = build_model(skel, cams, n_cams, opts, h->hm);
     if (s != CPE_OK) { delete h; return s; }
     HIPCHK(hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        // dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+        // dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+        const void* ks[] = {(const void*)&k_resjac<true, 4, 3, 2>, (const void*)&k_resjac<false, 4, 3, 2>,
+                            (const void*)&k_resjac<true, 4, 4, 2>, (const void*)&k_resjac<false, 4, 4, 2>};
+        for (const void* k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&h->dm, sizeof(DevModel)));
     HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
@@ -279,9 +290,24 @@ cpe_status cpe_eval_resjac(cpe_handle* h, int32_t B, int32_t N, const double* q,
     if (F == 0) return CPE_OK;
     if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
     HIPCHK(hipSetDevice(h->device));
-    const size_t lds = lds_resjac(h->hm);
-    if (cost) hipLaunchKernelGGL(k_resjac<true>, dim3((unsigned)F), dim3(WAVE), lds, h->stream, h->dm, N, q, meas, weight, r, J, eps, cost);
-    else hipLaunchKernelGGL(k_resjac<false>, dim3((unsigned)F), dim3(WAVE), lds, h->stream, h->dm, N, q, meas, weight, r, J, eps, cost);
+    const DevModel& m = h->hm;
+    if (m.C * m.L > RJ_MAXPASS * WAVE) return fail(CPE_BAD_ARG, "cpe_eval_resjac supports at most 256 (camera, marker) pairs");
+    constexpr int NW = 4;                                   // waves (= frames in flight) per workgroup
+    const size_t lds = sizeof(double) * (((rj_shared_doubles(m.C, m.L, m.S) + 1) & ~1) + (size_t)NW * rj_wave_doubles(m.C, m.L, m.nq, m.nl));
+    int wg_per_cu = (int)((160 * 1024) / lds);
+    if (wg_per_cu < 1) return fail(CPE_BAD_ARG, "model too large for the LDS of one workgroup");
+    // 2 workgroups (8 waves) per CU: the kernel needs ~200 VGPRs; capping it at 168 for 3 waves/SIMD spills
+    // and measures 25 % slower (profiles/r01_resjac_ablation.md)
+    constexpr int variant = 2;
+    if (wg_per_cu > variant) wg_per_cu = variant;
+    long grid = (long)h->n_cu * wg_per_cu;
+    const long need = (long)((F + NW - 1) / NW);
+    if (grid > need) grid = need;
+    const int npass = (m.C * m.L + WAVE - 1) / WAVE;
+#define RJ_LAUNCH(COST, NP, OC) hipLaunchKernelGGL((k_resjac<COST, NW, NP, OC>), dim3((unsigned)grid), dim3(WAVE * NW), lds, h->stream, h->dm, N, (long)F, q, meas, weight, r, J, eps, cost)
+    if (cost) { if (npass <= 3) RJ_LAUNCH(true, 3, 2); else RJ_LAUNCH(true, 4, 2); }
+    else { if (npass <= 3) RJ_LAUNCH(false, 3, 2); else RJ_LAUNCH(false, 4, 2); }
+#undef RJ_LAUNCH
     HIPCHK(hipGetLastError());
     return CPE_OK;
 }

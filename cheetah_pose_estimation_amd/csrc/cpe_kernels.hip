@@ -107,91 +107,195 @@ __device__ __forceinline__ int wave_project_joints(const DevModel* __restrict__ 
 }
 
 // --------------------------------------------------------------------------------------------------
-// metric 1 kernel.  One wave (= one workgroup) per frame.
-// dynamic LDS (doubles): q[nq] | sc[6 nl] | R[36 nl] | pos[3 L] | cam[23 C] | G[6 C L]
-template <bool WANT_COST>
-__global__ __launch_bounds__(WAVE) void k_resjac(const DevModel* __restrict__ M, int N,
-                                                 const double* __restrict__ q, const double* __restrict__ meas,
-                                                 const double* __restrict__ weight, double* __restrict__ r,
-                                                 double* __restrict__ J, double* __restrict__ eps,
-                                                 double* __restrict__ cost) {
+// metric 1 kernel: residual + sparse Jacobian + acceleration slack.
+//
+// Persistent workgroups of NW waves; every wave owns one frame at a time and walks the frame list with a
+// grid stride.  Read-only model tables (cameras, Jacobian-slot table, marker-chain table) are staged ONCE
+// per workgroup in LDS, so the per-frame code has no dependent global loads; the next frame's q / meas /
+// neighbour-q are prefetched into registers while the current frame computes and stores.
+// LDS (doubles): shared  cam[23C] | ident[10] | slot[4S] | chain[4*L*MAXCHAIN] | clen[(L+1)/2]
+//                per wave A[max(6CL, nq+6nl+36nl)] | pos[3L(+1)]   with A = {q, sin/cos, R & dR} later overlaid by G
+// Tables are structure-of-arrays so that consecutive lanes touch consecutive LDS words (no bank conflicts):
+//   slot:  v0[S] v1[S] v2[S] (double) | doff[S] marker[S] (int32; doff = offset of the 3x3 dR in the wave's R block, <0: identity)
+//   chain: v0[K][L] v1[K][L] v2[K][L] (double) | roff[K][L] (int32), K = CPE_MAX_CHAIN, marker index fastest
+#define RJ_MAXPASS 4
+
+__host__ __device__ inline int rj_shared_doubles(int C, int L, int S) {
+    return 23 * C + 10 + 3 * S + (2 * S + 1) / 2 + 3 * L * CPE_MAX_CHAIN + (L * CPE_MAX_CHAIN + 1) / 2 + (L + 1) / 2;
+}
+__host__ __device__ inline int rj_wave_doubles(int C, int L, int nq, int nl) {
+    const int a = 6 * C * L, b = nq + 6 * nl + 36 * nl;
+    return ((a > b ? a : b) + 3 * L + 3) & ~1;
+}
+
+template <bool WANT_COST, int NW, int NPASS, int OCC>
+__global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevModel* __restrict__ M, int N, long F,
+                                                      const double* __restrict__ q, const double* __restrict__ meas,
+                                                      const double* __restrict__ weight, double* __restrict__ r,
+                                                      double* __restrict__ J, double* __restrict__ eps,
+                                                      double* __restrict__ cost) {
     extern __shared__ double smem[];
-    const int lane = threadIdx.x;
-    const int nq = M->nq, nl = M->nl, L = M->L, C = M->C, S = M->S;
-    double* sq = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = M->nq, nl = M->nl, L = M->L, C = M->C, S = M->S, CL = C * L;
+    double* scam = smem;
+    double* sident = scam + 23 * C;
+    double* slv = sident + 10;                                              // slot vectors [3][S]
+    int* sli = reinterpret_cast<int*>(slv + 3 * S);                         // doff[S], marker[S]
+    double* chv = slv + 3 * S + (2 * S + 1) / 2;                            // chain vectors [3][K][L]
+    int* chr = reinterpret_cast<int*>(chv + 3 * L * CPE_MAX_CHAIN);         // roff[K][L]
+    int* sclen = reinterpret_cast<int*>(chv + 3 * L * CPE_MAX_CHAIN + (L * CPE_MAX_CHAIN + 1) / 2);
+    double* wbase = smem + ((rj_shared_doubles(C, L, S) + 1) & ~1);
+    const int nA = rj_wave_doubles(C, L, nq, nl) - ((3 * L + 3) & ~1) + 0;
+    double* wv = wbase + wave * rj_wave_doubles(C, L, nq, nl);
+    double* sq = wv;
     double* ssc = sq + nq;
     double* sR = ssc + 6 * nl;
-    double* spos = sR + 36 * nl;
-    double* scam = spos + 3 * L;
-    double* sG = scam + 23 * C;
-    const size_t f = blockIdx.x;
-    const double* qf = q + f * nq;
+    double* sG = wv;                       // overlays q / sincos / R once they are dead
+    double* spos = wv + nA;
 
-    if (lane < nq) sq[lane] = qf[lane];
-    for (int t = lane; t < 23 * C; t += WAVE) scam[t] = reinterpret_cast<const double*>(M->cam)[t];
-    wave_lds_sync();
-    wave_sincos(M, sq, ssc, lane);
-    wave_lds_sync();
-    wave_rotations(M, ssc, sR, lane);
-    wave_lds_sync();
-    wave_markers(M, sq, sR, spos, lane);
-
-    // d p / d q of my Jacobian slots stay in registers (slot s = lane + 64 i)
-    double dp0[5], dp1[5], dp2[5];
-    int mk[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-        const int s = lane + WAVE * i;
-        dp0[i] = dp1[i] = dp2[i] = 0.0; mk[i] = 0;
-        if (s < S) { mk[i] = M->slot_marker[s]; slot_dp(M, sR, s, dp0[i], dp1[i], dp2[i]); }
-    }
-    wave_lds_sync();
-
-    // project every (camera, marker) pair: residual out, d(u,v)/dp to LDS
-    const cpe_camera* cams = reinterpret_cast<const cpe_camera*>(scam);
-    const size_t pair0 = f * (size_t)(C * L);
-    double fc = 0.0;
-    for (int t = lane; t < C * L; t += WAVE) {
-        const int c = t / L, l = t - c * L;
-        double u, v, G[6];
-        project_point(cams[c], spos[3 * l], spos[3 * l + 1], spos[3 * l + 2], u, v, G);
-        const double2 z = reinterpret_cast<const double2*>(meas)[pair0 + t];
-        const double e0 = u - z.x, e1 = v - z.y;
-        reinterpret_cast<double2*>(r)[pair0 + t] = make_double2(e0, e1);
-#pragma unroll
-        for (int k = 0; k < 6; k++) sG[6 * t + k] = G[k];
-        if (WANT_COST) {
-            const double w = cams[c].mult * weight[pair0 + t];
-            fc += robust_loss(w * e0, M->loss_a, M->loss_b, M->loss_c, 0, false).rho
-                + robust_loss(w * e1, M->loss_a, M->loss_b, M->loss_c, 0, false).rho;
+    // ---- stage the model tables (once per workgroup)
+    for (int t = tid; t < 23 * C; t += WAVE * NW) scam[t] = reinterpret_cast<const double*>(M->cam)[t];
+    if (tid < 9) sident[tid] = (tid == 0 || tid == 4 || tid == 8) ? 1.0 : 0.0;
+    for (int s = tid; s < S; s += WAVE * NW) {
+        const int l = M->slot_marker[s], cpos = M->slot_cpos[s];
+        sli[S + s] = l;
+        if (cpos < 0) {
+            const int ax = M->slot_dof[s];
+            slv[s] = ax == 0 ? 1.0 : 0.0; slv[S + s] = ax == 1 ? 1.0 : 0.0; slv[2 * S + s] = ax == 2 ? 1.0 : 0.0; sli[s] = -1;
+        } else {
+            slv[s] = M->chain_vec[l][cpos][0]; slv[S + s] = M->chain_vec[l][cpos][1]; slv[2 * S + s] = M->chain_vec[l][cpos][2];
+            sli[s] = 9 * (4 * M->chain_link[l][cpos] + 1 + M->slot_ang[s]);
         }
     }
-    if (WANT_COST) {
-        fc = wave_sum(fc);
-        if (lane == 0) cost[f] = fc;
+    for (int t = tid; t < L * CPE_MAX_CHAIN; t += WAVE * NW) {
+        const int k = t / L, l = t - k * L;
+        const bool on = k < M->chain_len[l];
+        chv[t] = on ? M->chain_vec[l][k][0] : 0.0;
+        chv[L * CPE_MAX_CHAIN + t] = on ? M->chain_vec[l][k][1] : 0.0;
+        chv[2 * L * CPE_MAX_CHAIN + t] = on ? M->chain_vec[l][k][2] : 0.0;
+        chr[t] = on ? 36 * M->chain_link[l][k] : 0;
     }
-    wave_lds_sync();
+    for (int t = tid; t < L; t += WAVE * NW) sclen[t] = M->chain_len[t];
+    const double ih2 = M->ih2, la = M->loss_a, lb = M->loss_b, lc = M->loss_c;
+    __syncthreads();
 
-    // J[c][s][0..1] = G_{c,marker(s)} . dp_s : 16-byte stores, consecutive lanes -> consecutive slots
-    double2* Jf = reinterpret_cast<double2*>(J) + f * (size_t)(C * S);
-    for (int c = 0; c < C; c++) {
+    const cpe_camera* cams = reinterpret_cast<const cpe_camera*>(scam);
+    const long wstride = (long)gridDim.x * NW;
+    long f = (long)blockIdx.x * NW + wave;
+
+    // q of the NEXT frame is prefetched one frame ahead (it is needed at once); measurements and the three
+    // predecessor q's are loaded at the top of their own frame and consumed late, so their latency is covered.
+    double qreg = 0.0;
+    if (f < F && lane < nq) qreg = q[f * nq + lane];
+
+    while (f < F) {
+        if (lane < nq) sq[lane] = qreg;
+        const long fn = f + wstride;
+        double qn = 0.0, qp1 = 0.0, qp2 = 0.0, qp3 = 0.0;
+        double2 mz[NPASS];
+        const bool has_prev = (int)(f % N) >= 3;
+        if (lane < nq) {
+            if (fn < F) qn = q[fn * nq + lane];
+            if (has_prev) { const double* qf = q + f * nq + lane; qp1 = qf[-nq]; qp2 = qf[-2 * nq]; qp3 = qf[-3 * nq]; }
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            const int t = lane + WAVE * p;
+            if (t < CL) mz[p] = reinterpret_cast<const double2*>(meas)[f * CL + t];
+        }
+        wave_lds_sync();
+        wave_sincos(M, sq, ssc, lane);
+        wave_lds_sync();
+        for (int t = lane; t < 4 * nl; t += WAVE) rot_kind(ssc + 6 * (t >> 2), t & 3, sR + 9 * t);
+        wave_lds_sync();
+        // marker positions from the LDS chain table
+        if (lane < L) {
+            double p0 = sq[0], p1 = sq[1], p2 = sq[2];
+            const int n = sclen[lane];
+            const int KL = L * CPE_MAX_CHAIN;
+            for (int k = 0; k < n; k++) {
+                const int t = k * L + lane;
+                const double v0 = chv[t], v1 = chv[KL + t], v2 = chv[2 * KL + t];
+                const double* R = sR + chr[t];
+                p0 += R[0] * v0 + R[1] * v1 + R[2] * v2;
+                p1 += R[3] * v0 + R[4] * v1 + R[5] * v2;
+                p2 += R[6] * v0 + R[7] * v1 + R[8] * v2;
+            }
+            spos[3 * lane] = p0; spos[3 * lane + 1] = p1; spos[3 * lane + 2] = p2;
+        }
+        // d p / d q of my Jacobian slots (slot s = lane + 64 i) stay in registers
+        double dp0[5], dp1[5], dp2[5];
+        int mk[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             const int s = lane + WAVE * i;
+            dp0[i] = dp1[i] = dp2[i] = 0.0; mk[i] = 0;
             if (s < S) {
-                const double* G = sG + 6 * (c * L + mk[i]);
-                Jf[c * S + s] = make_double2(G[0] * dp0[i] + G[1] * dp1[i] + G[2] * dp2[i],
-                                             G[3] * dp0[i] + G[4] * dp1[i] + G[5] * dp2[i]);
+                const int doff = sli[s];
+                const double v0 = slv[s], v1 = slv[S + s], v2 = slv[2 * S + s];
+                const double* D = doff < 0 ? sident : sR + doff;
+                mk[i] = sli[S + s];
+                dp0[i] = D[0] * v0 + D[1] * v1 + D[2] * v2;
+                dp1[i] = D[3] * v0 + D[4] * v1 + D[5] * v2;
+                dp2[i] = D[6] * v0 + D[7] * v1 + D[8] * v2;
             }
         }
-    }
+        wave_lds_sync();        // R, sincos, q are dead from here: G may overlay them
 
-    // acceleration slack of the constant-acceleration model (free dq0/ddq0 => 0 for n < 3)
-    if (lane < nq) {
-        const int n = (int)(f % (size_t)N);
-        double e = 0.0;
-        if (n >= 3) e = (sq[lane] - 3.0 * qf[lane - nq] + 3.0 * qf[lane - 2 * nq] - qf[lane - 3 * nq]) * M->ih2;
-        eps[f * nq + lane] = e;
+        // project every (camera, marker) pair: residual out, d(u,v)/dp to LDS.  The J rows of a camera are
+        // stored as soon as all its pairs are projected, so the 26 KB of stores per frame are spread over the
+        // projection passes instead of arriving in one burst.
+        // J[c][s][0..1] = G_{c,marker(s)} . dp_s : 16-byte stores, consecutive lanes -> consecutive slots
+        const long pair0 = f * CL;
+        double2* Jf = reinterpret_cast<double2*>(J) + f * (long)(C * S);
+        double fc = 0.0;
+        int c_done = 0;
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            __builtin_amdgcn_sched_barrier(0);      // keep the passes sequential: interleaving them costs ~40 VGPRs
+            const int t = lane + WAVE * p;
+            if (t < CL) {
+                const int c = t / L, l = t - c * L;
+                double u, v, G[6];
+                project_point(cams[c], spos[3 * l], spos[3 * l + 1], spos[3 * l + 2], u, v, G);
+                const double e0 = u - mz[p].x, e1 = v - mz[p].y;
+                reinterpret_cast<double2*>(r)[pair0 + t] = make_double2(e0, e1);
+                double2* Gd = reinterpret_cast<double2*>(sG + 6 * t);
+                Gd[0] = make_double2(G[0], G[1]); Gd[1] = make_double2(G[2], G[3]); Gd[2] = make_double2(G[4], G[5]);
+                if (WANT_COST) {
+                    const double w = cams[c].mult * weight[pair0 + t];
+                    fc += robust_loss(w * e0, la, lb, lc, 0, false).rho + robust_loss(w * e1, la, lb, lc, 0, false).rho;
+                }
+            }
+            wave_lds_sync();
+            const int c_now = p == NPASS - 1 ? C : min(C, (WAVE * (p + 1)) / L);
+            for (int c = c_done; c < c_now; c++) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int s = lane + WAVE * i;
+                    if (s < S) {
+                        const double2* G = reinterpret_cast<const double2*>(sG + 6 * (c * L + mk[i]));
+                        const double2 g0 = G[0], g1 = G[1], g2 = G[2];
+                        Jf[c * S + s] = make_double2(g0.x * dp0[i] + g0.y * dp1[i] + g1.x * dp2[i],
+                                                     g1.y * dp0[i] + g2.x * dp1[i] + g2.y * dp2[i]);
+                    }
+                }
+            }
+            c_done = c_now;
+        }
+        if (WANT_COST) {
+            fc = wave_sum(fc);
+            if (lane == 0) cost[f] = fc;
+        }
+        // acceleration slack of the constant-acceleration model (free dq0/ddq0 => 0 for n < 3)
+        if (lane < nq) {
+            double e = 0.0;
+            if (has_prev) e = (qreg - 3.0 * qp1 + 3.0 * qp2 - qp3) * ih2;
+            eps[f * nq + lane] = e;
+        }
+        qreg = qn;
+        f = fn;
+        wave_lds_sync();        // G region is rewritten as q / sincos / R by the next frame
     }
 }
 
