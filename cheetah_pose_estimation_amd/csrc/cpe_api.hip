@@ -412,6 +412,16 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     return worst;
 }
 
+#ifdef CPE_LM_STAMPS
+// diagnostic build only: per-phase shader-clock totals accumulated by block 0 of k_lm_step since the last call
+cpe_status cpe_debug_lm_stamps(unsigned long long* out16) {
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lm_stamps), z, sizeof(z)));
+    return CPE_OK;
+}
+#endif
+
 // ---- host-pointer wrappers: stage through HBM (PCIe-inclusive; never the benchmarked path) -------------
 struct DevBuf {
     double* p = nullptr;

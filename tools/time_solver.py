@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer tool: time a fixed number of LM iterations of cpe_solve (per-kernel ablation builds can be
+selected with --lib).  Not part of the product or the tests."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None)
+ap.add_argument("--B", type=int, default=512)
+ap.add_argument("--N", type=int, default=200)
+ap.add_argument("--iters", type=int, default=10)
+args = ap.parse_args()
+import torch
+from cheetah_pose_estimation_amd import _lib, abi, skeleton, synth
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+sk = skeleton.build_skeleton("phantom", 25); cams = synth.make_cameras(6)
+opts = abi.default_options(); opts.max_iter = args.iters; opts.tol_step = 0.0; opts.tol_cost = 0.0; opts.max_outer = 0
+h = _lib.Handle(sk, cams, opts)
+d = synth.make_batch(sk, cams, B=16, N=args.N, seed=1)
+dev = torch.device("cuda", 0)
+rep = (args.B + 15) // 16
+T = {k: torch.tensor(d[k], device=dev).repeat((rep,) + (1,) * (d[k].ndim - 1))[:args.B].contiguous() for k in ("q_init", "meas", "weight")}
+q = torch.empty_like(T["q_init"]); dq = torch.empty_like(q); ddq = torch.empty_like(q)
+pos = torch.empty((args.B, args.N, 25, 3), dtype=torch.float64, device=dev); me = torch.empty((args.B, args.N, 6, 25, 2), dtype=torch.float64, device=dev)
+for rnd in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    st, stats = h.solve(T["q_init"], T["meas"], T["weight"], q, dq, ddq, pos, me)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+its = np.mean([s.iterations for s in stats])
+if hasattr(h.lib, "cpe_debug_lm_stamps"):
+    import ctypes as C
+    z = (C.c_ulonglong * 16)()
+    h.lib.cpe_debug_lm_stamps(z)
+    tot = sum(z) or 1
+    names = ["accept/reduce", "init rows", "chol", "trsm", "update+Lwrite", "store_row", "bwd partial", "bwd subst+storeL", "dot products", "q update"]
+    print("k_lm_step phase shares (block 0, last solve):", ", ".join(f"{n} {100.0 * z[i] / tot:.1f}%" for i, n in enumerate(names)), f" total cycles/launch {tot / max(its + 1, 1):.3g}")
+print(f"{os.path.basename(args.lib or 'libcpe.so'):28s} B={args.B} iters={its:.1f} total {el*1e3:8.2f} ms  per-iteration {el*1e3/max(its,1):7.3f} ms  cost0 {stats[0].cost:.6g}")
