@@ -60,8 +60,10 @@ def project_numpy(cam: abi.Camera, p: np.ndarray) -> np.ndarray:
     return np.stack([cam.fx * a * g + cam.cx, cam.fy * b * g + cam.cy], axis=-1), X[..., 2]
 
 
-def project_dependents_numpy(sk: abi.Skeleton, q: np.ndarray) -> np.ndarray:
-    """Closed-form solve of the joint equalities for the dependent angles; q[..., nq]."""
+def project_dependents_numpy(sk: abi.Skeleton, q: np.ndarray, branch=None) -> np.ndarray:
+    """Closed-form solve of the joint equalities for the dependent angles; q[..., nq].
+    `branch[..., n_joints]` (+1 / -1, default +1) selects the sign of cos(phi) of each revolute child: both
+    signs satisfy the equalities; +1 is the branch reached from the reference's initial guess."""
     q = q.copy()
     for j in range(sk.n_joints):
         p, c = sk.joint_parent[j], sk.joint_child[j]
@@ -72,6 +74,8 @@ def project_dependents_numpy(sk: abi.Skeleton, q: np.ndarray) -> np.ndarray:
         if sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y:
             sphi = np.clip(az / ct, -1, 1)
             phi = np.arcsin(sphi)
+            if branch is not None:
+                phi = np.where(np.asarray(branch)[..., j] < 0, np.pi - phi, phi)
             psi = np.arctan2(ay, ax) - np.arctan2(np.cos(phi), sphi * st)
             ref = q[..., 3 + 3 * p + 2]
             psi = psi + 2 * np.pi * np.round((ref - psi) / (2 * np.pi))

@@ -1,0 +1,73 @@
+"""FK / marker / joint-equality / fisheye model pinned against the reference's STORED outputs.
+
+tests/golden/fk_csv_pin.npz holds `uv` = the numbers of data/test_set/2019_03_07/phantom/run/fte_kinematic/
+cam{1..6}_fte.csv (the reference's own 2D reprojection of its own FK at its solution, 57 frames x 6 cameras x
+24 markers) together with joint angles q and 6 x 14 camera parameters RECOVERED from those numbers alone by
+tools/pin_fk_from_csv.py (two-view geometry -> bundle adjustment -> skeleton fit -> joint refinement).
+If the FK chain, a link length, a marker offset, a joint axis or the projection formula were restated wrongly,
+no (q, cameras) could reproduce the 16 416 stored values; the recovered ones do to < 1e-4 px."""
+import os
+
+import numpy as np
+
+from cheetah_pose_estimation_amd import abi, skeleton, synth
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fk_csv_pin.npz"))
+
+
+def _rodrigues(r):
+    th = np.linalg.norm(r)
+    k = r / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def _cams():
+    cams = (abi.Camera * 6)()
+    for c in range(6):
+        p = Z["cams"][c]
+        cam = cams[c]
+        cam.model = abi.CAM_FISHEYE
+        cam.fx, cam.fy, cam.cx, cam.cy = p[0:4]
+        for i in range(4):
+            cam.D[i] = p[4 + i]
+        R = _rodrigues(p[8:11]) if np.linalg.norm(p[8:11]) > 0 else np.eye(3)
+        for i in range(9):
+            cam.R[i] = R.reshape(-1)[i]
+        for i in range(3):
+            cam.t[i] = p[11 + i]
+        cam.mult = 1.0
+    return cams
+
+
+def test_oracle_fk_and_projection_reproduce_the_stored_2d_files(oracle):
+    sk = skeleton.build_skeleton(str(Z["animal"]), 24)
+    q, uv = Z["q"], Z["uv"]
+    assert uv.shape == (57, 6, 24, 2) and q.shape == (57, 54)
+    cams = _cams()
+    pos = oracle.markers(sk, q)                                   # C oracle FK + marker model
+    got = np.array([[[oracle.project(cams[c], pos[n, l]) for l in range(24)] for c in range(6)] for n in range(57)])
+    err = np.abs(got - uv)
+    assert err.max() < 1e-4, err.max()                            # all 16 416 stored numbers
+    assert np.sqrt((err ** 2).mean()) < 5e-6
+    # the recovered angles satisfy the reference's 26 joint equalities (both cos(phi) branches occur in this run)
+    c = np.array([np.abs(oracle.constraints(sk, x)).max() for x in q])
+    assert c.max() < 1e-12
+    assert (Z["branch"] < 0).sum() > 0
+    # link lengths implied by the stored files equal cheetah_params.py (the 3D markers of one link keep their distance)
+    p = skeleton.load_params("phantom")
+    M = {m: i for i, m in enumerate(skeleton.MARKERS)}
+    for a, b, Lref in (("tail1", "tail2", p["tail1"]["length"]), ("tail_base", "tail1", p["tail0"]["length"]),
+                       ("spine", "tail_base", p["body_B"]["length"]), ("spine", "neck_base", p["body_F"]["length"]),
+                       ("r_front_knee", "r_front_ankle", p["front"]["calf"]["length"]), ("l_back_ankle", "l_back_paw", p["back"]["hock"]["length"])):
+        dist = np.linalg.norm(pos[:, M[a]] - pos[:, M[b]], axis=1)
+        assert np.abs(dist - Lref).max() < 1e-12
+
+
+def test_numpy_host_fk_agrees_on_the_recovered_angles():
+    sk = skeleton.build_skeleton(str(Z["animal"]), 24)
+    cams = _cams()
+    pos, _ = synth.fk_numpy(sk, Z["q"])
+    for c in range(6):
+        uv, _ = synth.project_numpy(cams[c], pos)
+        assert np.abs(uv - Z["uv"][:, c]).max() < 1e-4

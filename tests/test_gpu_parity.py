@@ -168,3 +168,17 @@ def test_estimator_api_end_to_end_from_files(tmp_path, oracle):
     got = rows[:, 1:].reshape(30, 24, 3)[:, :, :2]
     ok = np.isfinite(got)
     assert np.abs(got[ok] - uv[ok]).max() < 1e-9
+
+
+def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_factory):
+    """HIP FK + fisheye projection against the reference's own stored reprojections
+    (tests/golden/fk_csv_pin.npz, see tests/test_fk_pin.py): with `meas` = the stored cam*_fte.csv values the
+    residual returned by k_resjac must vanish for all 57 x 6 x 24 points."""
+    import os
+    from test_fk_pin import Z, _cams
+    sk = skeleton.build_skeleton(str(Z["animal"]), 24)
+    h = gpu_handle_factory(sk, _cams())
+    q = Z["q"][None]
+    meas = np.ascontiguousarray(Z["uv"][None])
+    r, J, eps, cost = h.eval_resjac_host(q, meas, np.ones((1, 57, 6, 24)))
+    assert np.abs(r).max() < 1e-4 and np.sqrt((r ** 2).mean()) < 5e-6
