@@ -67,6 +67,7 @@ def load():
     lib.cpe_eval_resjac_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_project_joints.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.cpe_forward_kinematics.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.cpe_eval_normal.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     _LIB = lib
@@ -150,6 +151,10 @@ class Handle:
     def forward_kinematics(self, q, positions, com=None):
         _check(self.lib.cpe_forward_kinematics(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(positions), _ptr(com)),
                "cpe_forward_kinematics")
+
+    def eval_normal(self, q, meas, weight, g, Bm, cost, gam=None, q_out=None):
+        _check(self.lib.cpe_eval_normal(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(meas), _ptr(weight), _ptr(g), _ptr(Bm), _ptr(cost),
+                                        _ptr(gam), _ptr(q_out)), "cpe_eval_normal")
 
     def solve(self, q_init, meas, weight, q, dq, ddq, positions, meas_err):
         B, N = q_init.shape[0], q_init.shape[1]

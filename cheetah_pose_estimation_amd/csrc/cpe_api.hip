@@ -29,7 +29,7 @@ struct cpe_handle {
     // solver workspace
     size_t ws_frames = 0; int ws_B = 0;
     double *qbuf = nullptr, *gbuf = nullptr, *Bbuf = nullptr, *costbuf = nullptr, *Lbuf = nullptr, *zbuf = nullptr,
-           *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr;
+           *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr, *gambuf = nullptr;
     SeqState* st = nullptr;
     int* flag = nullptr;
 };
@@ -145,8 +145,29 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             m.scol_n[r] = n;
         }
     }
+    // revolute (leg) links: R_c = R_body Ry(alpha_c)
+    std::vector<int> rev_of_link(nl, -1);
+    m.nrev = 0;
+    for (int p = 0; p < nq; p++) m.euler_rev[p] = -1;
+    for (int k = 0; k < nu; k++) { m.rev_of_u[k] = -1; m.ucoord_src[k] = m.indep[k]; m.bodyang_j[k] = -1; m.bodyang_legs_n[k] = 0; }
+    for (int j = 0; j < s->n_joints; j++)
+        if (m.joint_kind[j] == CPE_JOINT_REVOLUTE_Y) {
+            const int r = m.nrev++, c = m.joint_child[j], Bk = m.joint_body[j];
+            rev_of_link[c] = r;
+            m.rev_child[r] = c; m.rev_body[r] = Bk; m.rev_u[r] = m.u_of_q[3 + 3 * c + 1];
+            m.rev_of_u[m.rev_u[r]] = r; m.euler_rev[3 + 3 * c + 1] = r;
+            for (int a = 0; a < 3; a++) {
+                const int kb = m.u_of_q[3 + 3 * Bk + a];
+                m.rev_body_u[r][a] = kb; m.bodyang_j[kb] = a;
+                m.bodyang_legs[kb][m.bodyang_legs_n[kb]++] = r;
+            }
+        }
+    m.ns = nq + m.nrev;
+    for (int r = 0; r < m.nrev; r++) m.ucoord_src[m.rev_u[r]] = nq + r;
+    m.n_trunk = 0;
+    for (int i = 0; i < nl; i++) if (rev_of_link[i] < 0) m.trunk_link[m.n_trunk++] = i;
     // marker chains and Jacobian slots
-    int S = 0, mct = 0;
+    int S = 0, mct = 0, ss = 0, sv = 0;
     for (int l = 0; l < L; l++) {
         int chain[CPE_MAX_LINKS], n = 0, k = s->marker_link[l];
         if (k < 0 || k >= nl) return fail(CPE_BAD_ARG, "bad marker link");
@@ -164,7 +185,9 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
         for (int d = 0; d < 3; d++) { m.slot_marker[S] = l; m.slot_dof[S] = d; m.slot_cpos[S] = -1; m.slot_ang[S] = 0; S++; }
         for (int i = 0; i < n; i++)
             for (int a = 0; a < 3; a++) { m.slot_marker[S] = l; m.slot_dof[S] = 3 + 3 * m.chain_link[l][i] + a; m.slot_cpos[S] = i; m.slot_ang[S] = a; S++; }
-        // reduced columns and their terms
+        // ---- solver side: reduced columns of this marker.  Leg links are rotations of their body about its
+        // y axis (R_c = R_B Ry(alpha_c)); everything the legs contribute is a body matrix times a body-frame
+        // vector that depends on the alphas ("dynamic vectors").
         int nc = 0;
         auto col_index = [&](int col) -> int {
             for (int e = 0; e < nc; e++) if (m.mcol[l][e] == col) return e;
@@ -177,16 +200,60 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             m.term_slot[l][e][m.term_n[l][e]] = (int16_t)slot; m.term_s[l][e][m.term_n[l][e]] = (int16_t)sidx; m.term_n[l][e]++;
             return true;
         };
+        auto new_slot = [&](int moff, int vdyn, const double* v) -> int {
+            if (ss >= CPE_MAX_SLOTS) return -1;
+            m.ss_moff[ss] = moff; m.ss_vdyn[ss] = vdyn;
+            for (int d = 0; d < 3; d++) m.ss_vec[ss][d] = v ? v[d] : 0.0;
+            return ss++;
+        };
         bool ok = true;
-        for (int sl = m.slot_off[l]; sl < S && ok; sl++) {
-            const int p = m.slot_dof[sl];
-            if (m.u_of_q[p] >= 0) ok = add_term(m.u_of_q[p], sl, -1);
-            else { const int r = m.dep_of_q[p]; for (int e = 0; e < m.scol_n[r] && ok; e++) ok = add_term(m.scol[r][e], sl, r * CPE_MAX_SCOL + e); }
+        const double ex[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int d = 0; d < 3 && ok; d++) { const int sl = new_slot(-1, -1, ex[d]); ok = sl >= 0 && add_term(m.u_of_q[d], sl, -1); }
+        int n_trunk_chain = 0;
+        while (n_trunk_chain < n && rev_of_link[m.chain_link[l][n_trunk_chain]] < 0) n_trunk_chain++;
+        m.pc_len[l] = n_trunk_chain; m.pw_id[l] = -1; m.pw_body[l] = 0;
+        for (int i = 0; i < n_trunk_chain && ok; i++) {
+            const int link = m.chain_link[l][i];
+            m.pc_link[l][i] = link;
+            for (int d = 0; d < 3; d++) m.pc_vec[l][i][d] = m.chain_vec[l][i][d];
+            for (int a = 0; a < 3 && ok; a++) {
+                const int sl = new_slot(9 * (4 * link + 1 + a), -1, m.chain_vec[l][i]);
+                const int p = 3 + 3 * link + a;
+                if (sl < 0) { ok = false; break; }
+                if (m.u_of_q[p] >= 0) ok = add_term(m.u_of_q[p], sl, -1);
+                else { const int r = m.dep_of_q[p]; for (int e = 0; e < m.scol_n[r] && ok; e++) ok = add_term(m.scol[r][e], sl, r * CPE_MAX_SCOL + e); }
+            }
+        }
+        if (n_trunk_chain < n && ok) {
+            const int Bk = m.chain_link[l][n_trunk_chain - 1];
+            const int nleg = n - n_trunk_chain;
+            if (nleg > 3 || sv + 1 + nleg > CPE_MAX_SDYN) return fail(CPE_BAD_ARG, "leg chain too long");
+            const int wid = sv++;
+            m.sv_kind[wid] = 0; m.sv_cnt[wid] = nleg;
+            for (int i = 0; i < nleg; i++) {
+                const int link = m.chain_link[l][n_trunk_chain + i];
+                if (rev_of_link[link] < 0 || m.rev_body[rev_of_link[link]] != Bk) return fail(CPE_BAD_ARG, "leg links must follow their body in the marker chain");
+                m.sv_rev[wid][i] = rev_of_link[link];
+                for (int d = 0; d < 3; d++) m.sv_vec[wid][i][d] = m.chain_vec[l][n_trunk_chain + i][d];
+            }
+            m.pw_id[l] = wid; m.pw_body[l] = Bk;
+            for (int a = 0; a < 3 && ok; a++) {           // body angles act on the whole leg vector
+                const int sl = new_slot(9 * (4 * Bk + 1 + a), wid, nullptr);
+                ok = sl >= 0 && add_term(m.u_of_q[3 + 3 * Bk + a], sl, -1);
+            }
+            for (int i = 0; i < nleg && ok; i++) {        // alpha of each leg link
+                const int did = sv++;
+                m.sv_kind[did] = 1; m.sv_cnt[did] = 1; m.sv_rev[did][0] = m.sv_rev[wid][i];
+                for (int d = 0; d < 3; d++) m.sv_vec[did][0][d] = m.sv_vec[wid][i][d];
+                const int sl = new_slot(9 * (4 * Bk), did, nullptr);
+                ok = sl >= 0 && add_term(m.rev_u[m.sv_rev[wid][i]], sl, -1);
+            }
         }
         if (!ok) return fail(CPE_BAD_ARG, "marker depends on too many reduced dofs");
         m.mcol_n[l] = nc; m.mcol_off[l] = mct;
         for (int e = 0; e < nc; e++) { m.mc_marker[mct] = (int16_t)l; m.mc_j[mct] = (int16_t)e; mct++; }
     }
+    m.ss_n = ss; m.sv_n = sv;
     m.slot_off[L] = S; m.S = S; m.mcol_off[L] = mct; m.mc_total = mct;
     if (S > 5 * WAVE) return fail(CPE_BAD_ARG, "more than 320 Jacobian slots");
     for (int bnd = 0; bnd < s->n_bounds; bnd++) {
@@ -201,7 +268,8 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
 
 static size_t lds_fk(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C); }
 static size_t lds_normal(const DevModel& m) {
-    return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C + 3 * m.S + CPE_MAX_SCOL * m.ndep + 9 * m.L + 3 * m.mc_total + m.nu * m.nu + m.nu);
+    return sizeof(double) * (m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.nl + 3 * m.L + 23 * m.C + 3 * m.sv_n + GAM_STRIDE * m.nrev + 3 * m.ss_n +
+                             CPE_MAX_SCOL * m.ndep + 9 * m.L + 3 * m.mc_total + m.nu * m.nu + m.nu);
 }
 
 extern "C" {
@@ -245,9 +313,9 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
 }
 
 static void free_ws(cpe_handle* h) {
-    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->st};
+    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = nullptr; h->st = nullptr;
+    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = nullptr; h->st = nullptr;
     h->ws_frames = 0; h->ws_B = 0;
 }
 
@@ -341,7 +409,8 @@ static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     if (F <= h->ws_frames && B <= h->ws_B) return CPE_OK;
     free_ws(h);
     const int nq = h->hm.nq, nu = h->hm.nu;
-    HIPCHK(hipMalloc(&h->qbuf, sizeof(double) * 2 * F * nq));
+    HIPCHK(hipMalloc(&h->qbuf, sizeof(double) * 2 * F * h->hm.ns));
+    HIPCHK(hipMalloc(&h->gambuf, sizeof(double) * 2 * F * (size_t)(GAM_STRIDE * (h->hm.nrev > 0 ? h->hm.nrev : 1))));
     HIPCHK(hipMalloc(&h->gbuf, sizeof(double) * 2 * F * nu));
     HIPCHK(hipMalloc(&h->Bbuf, sizeof(double) * 2 * F * nu * nu));
     HIPCHK(hipMalloc(&h->costbuf, sizeof(double) * 2 * F * COST_STRIDE));
@@ -352,6 +421,29 @@ static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     HIPCHK(hipMalloc(&h->cmax, sizeof(double) * F));
     HIPCHK(hipMalloc(&h->st, sizeof(SeqState) * B));
     h->ws_frames = F; h->ws_B = B;
+    return CPE_OK;
+}
+
+static cpe_status ensure_ws(cpe_handle* h, int B, int N);
+
+cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
+                           double* g, double* Bm, double* cost, double* gam, double* q_out) {
+    if (!h || !q || !meas || !weight || !g || !Bm || !cost) return fail(CPE_BAD_ARG, "null argument");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    cpe_status s = ensure_ws(h, B, N);
+    if (s != CPE_OK) return s;
+    const DevModel& m = h->hm;
+    hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q, h->qbuf);
+    HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
+    HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf);
+    HIPCHK(hipMemcpyAsync(g, h->gbuf, sizeof(double) * F * m.nu, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(Bm, h->Bbuf, sizeof(double) * F * m.nu * m.nu, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_gather_normal, dim3((unsigned)F), dim3(128), 0, h->stream, h->dm, F, h->qbuf, h->costbuf, h->gambuf, cost, gam, q_out);
+    HIPCHK(hipGetLastError());
     return CPE_OK;
 }
 
@@ -368,21 +460,21 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     if (s != CPE_OK) return s;
     const DevModel& m = h->hm;
     const size_t Fw = F;   // buffers are laid out for exactly this call's F (strides use F)
-    HIPCHK(hipMemcpyAsync(h->qbuf, q_init, sizeof(double) * F * m.nq, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q_init, h->qbuf);   // Euler q -> (q, alpha)
     HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     LmParams prm;
     prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
     prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.pad = 0;
     const size_t ldsn = lds_normal(m);
-    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu);
-    hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 1, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf);
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf);
+    hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 1, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf);
     HIPCHK(hipGetLastError());
     std::vector<SeqState> hs(B);
     const int rounds = h->opts.max_iter + 2 * (h->opts.max_outer > 0 ? h->opts.max_outer : 0);   // a multiplier update costs one extra round
     for (int it = 0; it < rounds; it++) {
-        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu);
-        hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 0, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf);
+        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf);
+        hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 0, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf);
         if ((it & 7) == 7 || it == rounds - 1) {
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));

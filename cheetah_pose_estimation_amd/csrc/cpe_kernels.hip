@@ -68,10 +68,10 @@ __device__ __forceinline__ void slot_dp(const DevModel* __restrict__ M, const do
 // child.y = +parent.y reached from the reference's initial guess, acinoset_opt.py:574-583).
 // Updates sq and ssc in place; returns non-zero in every lane if some revolute child sits in the gimbal
 // band |cos(theta)| < |a_z| where the equalities have no solution.
-__device__ __forceinline__ int wave_project_joints(const DevModel* __restrict__ M, double* sq, double* ssc, int lane) {
+__device__ __forceinline__ int wave_project_joints(const DevModel* __restrict__ M, double* sq, double* ssc, int lane, bool hooke_only = false) {
     int clamped = 0;
     for (int level = 0; level < 2; level++) {
-        if (lane < M->nj) {
+        if (lane < M->nj && !(hooke_only && M->joint_kind[lane] == CPE_JOINT_REVOLUTE_Y)) {
             const int kind = M->joint_kind[lane], p = M->joint_parent[lane], c = M->joint_child[lane];
             const bool lvl1 = kind == CPE_JOINT_HOOKE_YZ && M->dep_of_q[3 + 3 * p] >= 0;   // parent phi is itself dependent
             if ((level == 1) == lvl1) {

@@ -11,6 +11,7 @@
 #define CPE_MAX_TERMS 8     // terms of one reduced marker-Jacobian column (1 direct + dependent angles)
 #define CPE_MAX_DEP 32      // dependent angles (26)
 #define CPE_MAX_SCOL 8      // columns of one row of S = d(dependent)/d(independent)
+#define CPE_MAX_SDYN 48     // dynamic (alpha-dependent) body-frame vectors of the leg markers
 
 struct DevModel {
     int32_t nl, L, C, nq, nu, S, nj, nb, ndep, curvature;
@@ -76,6 +77,28 @@ struct DevModel {
     int16_t hk_chain[CPE_MAX_DEP][CPE_MAX_SCOL];
     int32_t dep_joint[CPE_MAX_DEP];      // joint that defines dependent row r
     int32_t dep_level[CPE_MAX_DEP];      // 0: parent fully independent (or revolute); 1: parent's phi dependent
+
+    // ---- solver parametrisation: leg link c = body B rotated about B's y axis by alpha_c.
+    // State of one frame: ns = nq + nrev doubles = Euler q followed by the leg angles alpha.
+    int32_t nrev, ns, n_trunk, ss_n, sv_n;
+    int32_t rev_child[CPE_MAX_JOINTS], rev_body[CPE_MAX_JOINTS], rev_u[CPE_MAX_JOINTS];
+    int32_t rev_body_u[CPE_MAX_JOINTS][3];          // reduced index of the body's phi, theta, psi
+    int32_t rev_of_u[CPE_NX];                       // -1 or revolute index
+    int32_t ucoord_src[CPE_NX];                     // position of reduced coordinate k in the state vector
+    int32_t euler_rev[CPE_MAX_NQ];                  // revolute index if Euler dof p is a leg pitch theta_c, else -1
+    int32_t bodyang_j[CPE_NX];                      // k is angle j (0..2) of a body that carries legs, else -1
+    int32_t bodyang_legs_n[CPE_NX];
+    int32_t bodyang_legs[CPE_NX][CPE_MAX_JOINTS];
+    int32_t trunk_link[CPE_MAX_LINKS];              // links whose R / dR are needed (not leg links)
+    // dynamic body-frame vectors: kind 0: sum_i Ry(alpha_{rev[i]}) vec[i] ; kind 1: dRy/dalpha(alpha_{rev[0]}) vec[0]
+    int32_t sv_kind[CPE_MAX_SDYN], sv_cnt[CPE_MAX_SDYN], sv_rev[CPE_MAX_SDYN][3];
+    double sv_vec[CPE_MAX_SDYN][3][3];
+    // marker position: x + sum_k R_{pc_link} pc_vec + (pw_id >= 0 ? R_{pw_body} dyn[pw_id] : 0)
+    int32_t pc_len[CPE_MAX_MARKERS], pc_link[CPE_MAX_MARKERS][CPE_MAX_CHAIN], pw_id[CPE_MAX_MARKERS], pw_body[CPE_MAX_MARKERS];
+    double pc_vec[CPE_MAX_MARKERS][CPE_MAX_CHAIN][3];
+    // solver Jacobian slots: dp = Mat(ss_moff) * (ss_vdyn < 0 ? ss_vec : dyn[ss_vdyn]); ss_moff < 0: identity
+    int32_t ss_moff[CPE_MAX_SLOTS], ss_vdyn[CPE_MAX_SLOTS];
+    double ss_vec[CPE_MAX_SLOTS][3];
 };
 
 // per-sequence Levenberg-Marquardt state (device global memory)

@@ -87,6 +87,36 @@ def project_dependents_numpy(sk: abi.Skeleton, q: np.ndarray, branch=None) -> np
     return q
 
 
+def leg_layout(sk: abi.Skeleton):
+    """[(child link, body link)] of every revolute (leg) joint, in joint order; the body is the link whose y axis the
+    whole leg shares (cheetah.py:71-72,101)."""
+    body_of, out = {}, []
+    for j in range(sk.n_joints):
+        if sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y:
+            p, c = sk.joint_parent[j], sk.joint_child[j]
+            body_of[c] = body_of.get(p, p)
+            out.append((c, body_of[c]))
+    return out
+
+
+def legs_from_alpha(sk: abi.Skeleton, q: np.ndarray, alpha: np.ndarray) -> np.ndarray:
+    """Euler angles of the leg links from their rotation alpha[..., nrev] about the body's y axis:
+    R_c = R_B Ry(alpha) (principal pitch |theta_c| <= 90 deg, phi_c in (-180, 180] deg)."""
+    q = q.copy()
+    for r, (c, B) in enumerate(leg_layout(sk)):
+        RB = rot_zyx(q[..., 3 + 3 * B:6 + 3 * B])
+        ca, sa = np.cos(alpha[..., r]), np.sin(alpha[..., r])
+        Ry = np.zeros(alpha.shape[:-1] + (3, 3))
+        Ry[..., 0, 0] = ca; Ry[..., 0, 2] = sa; Ry[..., 1, 1] = 1.0; Ry[..., 2, 0] = -sa; Ry[..., 2, 2] = ca
+        Rc = RB @ Ry
+        q[..., 3 + 3 * c + 1] = np.arcsin(np.clip(-Rc[..., 2, 0], -1, 1))
+        q[..., 3 + 3 * c] = np.arctan2(Rc[..., 2, 1], Rc[..., 2, 2])
+        psi = np.arctan2(Rc[..., 1, 0], Rc[..., 0, 0])
+        ref = q[..., 3 + 3 * B + 2]
+        q[..., 3 + 3 * c + 2] = psi + 2 * np.pi * np.round((ref - psi) / (2 * np.pi))
+    return q
+
+
 # ---------------------------------------------------------------------------------------------------
 def look_at_camera(pos, target, fx, fy, cx, cy, D, model=abi.CAM_FISHEYE, mult=1.0) -> abi.Camera:
     pos, target = np.asarray(pos, float), np.asarray(target, float)
@@ -126,7 +156,7 @@ def make_cameras(n_cams: int = 6, seed: int = 1234, track: float = 20.0):
     return cams
 
 
-def truth_trajectory(sk: abi.Skeleton, N: int, fps: float, rng: np.random.Generator, speed: float = 12.0):
+def truth_trajectory(sk: abi.Skeleton, N: int, fps: float, rng: np.random.Generator, speed: float = 12.0, wide_limbs: bool = False):
     """Ground-truth q[N, nq]: base x = speed*t, z = 0.55 + 0.03 sin(2 pi 3 t), limb pitch sinusoids at
     3 Hz inside the reference's joint ranges (cheetah.py:333-352); limb roll/yaw from the joint
     equalities."""
@@ -169,12 +199,30 @@ def truth_trajectory(sk: abi.Skeleton, N: int, fps: float, rng: np.random.Genera
         for n, th in ((U, thU), (Lk, thL), (H, thH)):
             q[:, dof(n, THETA)] = th
             q[:, dof(n, PSI)] = q[:, dof(body, PSI)]
-    return project_dependents_numpy(sk, q)
+    q = project_dependents_numpy(sk, q)
+    if wide_limbs:
+        # limbs swinging through and beyond the horizontal under a rolled trunk (as in the stored AcinoSet runs,
+        # tests/golden/fk_csv_pin.npz): generated in the leg-angle coordinates alpha, where this is smooth
+        q[:, dof("base", PHI)] += 0.2
+        q[:, dof("bodyF", PHI)] += 0.15
+        lay = leg_layout(sk)
+        alpha = np.zeros((N, len(lay)))
+        for r, (c, B) in enumerate(lay):
+            alpha[:, r] = q[:, 3 + 3 * c + 1] - q[:, 3 + 3 * B + 1]
+            if LINKS[c][0] in "LH":
+                alpha[:, r] *= 2.0                                        # calves and hocks: up to ~2.2 rad
+        q = legs_from_alpha(sk, q, alpha)
+        qh = project_dependents_numpy(sk, q)                              # tails: hooke phi from the (rolled) parent
+        for j in range(sk.n_joints):
+            if sk.joint_kind[j] == abi.JOINT_HOOKE_YZ:
+                c = sk.joint_child[j]
+                q[:, 3 + 3 * c] = qh[:, 3 + 3 * c]
+    return q
 
 
 def make_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0, seed: int = 1234,
                noise_px: float = 2.0, outlier_frac: float = 0.10, init_noise: float = 0.05,
-               dlc_thresh: float = 0.5, kinetic_dataset: bool = False):
+               dlc_thresh: float = 0.5, kinetic_dataset: bool = False, wide_limbs: bool = False):
     """B independent sequences (sequence b uses seed + b).  Returns dict of C-contiguous fp64 arrays:
     q_true, q_init [B,N,nq]; meas [B,N,C,L,2]; weight [B,N,C,L]."""
     C, L, nq = len(cams), sk.n_markers, sk.nq
@@ -183,7 +231,7 @@ def make_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0,
     sigma = measurement_sigma(L, kinetic_dataset)
     for b in range(B):
         rng = np.random.default_rng(seed + b)
-        qt = truth_trajectory(sk, N, fps, rng)
+        qt = truth_trajectory(sk, N, fps, rng, wide_limbs=wide_limbs)
         q_true[b] = qt
         pos, _ = fk_numpy(sk, qt)
         for c in range(C):

@@ -437,31 +437,124 @@ double cpo_gmm_cost(const cpe_priors* pr, const double* x22, double* grad) { ret
 
 /* ------------------------------------------------------------------------------------------------ */
 /* per-frame terms in reduced coordinates u (independent dofs): cost, gradient g[nu], PSD block Bm[nu][nu] */
+/* ------------------------------------------------------------------------------------------------ */
+/* Reduced coordinates of the solver.  The 28 coordinates u' are: the independent Euler
+ * dofs of the trunk (base 6, bodyF 3, neck 3, theta/psi of both tails) and, for every leg link c, its
+ * rotation alpha_c about the y axis of the body B the leg hangs from:  R_c = R_B * Ry(alpha_c).
+ * This satisfies the two revolute equalities of every leg joint identically (child.y = body.y) and,
+ * unlike the absolute Euler pitch theta_c, covers BOTH solution branches of those equalities smoothly
+ * (real runs swing limbs through +-90 deg of pitch: tests/golden/fk_csv_pin.npz).  alpha_c sits at the
+ * position of theta_c in the coordinate vector.  State of one frame: st[nq + nrev] = Euler q (54, kept
+ * consistent by state_sync) followed by the nrev leg angles alpha. */
 typedef struct {
     const cpe_skeleton* s; const cpe_camera* cams; int C; const cpe_options* o; const cpe_priors* pr;
     int nq, nu, indep[CPE_MAX_NQ], dep[CPE_MAX_NQ], u_of_q[CPE_MAX_NQ];
+    int nrev, ns;                 /* revolute (leg) links, state size nq + nrev */
+    int rev_joint[CPE_MAX_JOINTS];/* joint index of revolute r */
+    int rev_body[CPE_MAX_JOINTS]; /* body link whose y axis the leg shares */
+    int rev_of_u[CPE_NX];         /* u' index -> revolute index, or -1 for a plain Euler coordinate */
 } ctx_t;
 
 static void ctx_init(ctx_t* x, const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr) {
     x->s = s; x->cams = cams; x->C = C; x->o = o; x->pr = pr; x->nq = NQ(s);
     x->nu = cpo_split_dofs(s, x->indep, x->dep);
     for (int p = 0; p < x->nq; p++) x->u_of_q[p] = -1;
-    for (int k = 0; k < x->nu; k++) x->u_of_q[x->indep[k]] = k;
+    for (int k = 0; k < x->nu; k++) { x->u_of_q[x->indep[k]] = k; x->rev_of_u[k] = -1; }
+    x->nrev = 0;
+    int body_of_link[CPE_MAX_LINKS];
+    for (int i = 0; i < s->n_links; i++) body_of_link[i] = -1;
+    for (int j = 0; j < s->n_joints; j++)
+        if (s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y) {
+            int p = s->joint_parent[j], c = s->joint_child[j];
+            int body = body_of_link[p] >= 0 ? body_of_link[p] : p;
+            body_of_link[c] = body;
+            x->rev_joint[x->nrev] = j; x->rev_body[x->nrev] = body;
+            x->rev_of_u[x->u_of_q[3 + 3 * c + 1]] = x->nrev;
+            x->nrev++;
+        }
+    x->ns = x->nq + x->nrev;
+}
+
+static void mat3mul(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static double wrap_pi(double a) { return a - 2 * M_PI * round(a / (2 * M_PI)); }
+
+/* Euler q of the whole skeleton from the trunk coordinates (in st[0..nq)) and the leg angles alpha */
+static void state_sync(const ctx_t* x, double* st) {
+    const cpe_skeleton* s = x->s;
+    for (int r = 0; r < x->nrev; r++) {
+        int c = s->joint_child[x->rev_joint[r]], B = x->rev_body[r];
+        double RB[9], Rc[9], al = st[x->nq + r], ca = cos(al), sa = sin(al);
+        double Ry[9] = {ca, 0, sa, 0, 1, 0, -sa, 0, ca};
+        cpo_rot(st + 3 + 3 * B, RB);
+        mat3mul(RB, Ry, Rc);
+        double* e = st + 3 + 3 * c;
+        double sth = -Rc[6]; if (sth > 1) sth = 1; if (sth < -1) sth = -1;
+        e[1] = asin(sth);                       /* principal pitch: the continuous path of the reference's Euler angles */
+        e[0] = atan2(Rc[7], Rc[8]);
+        e[2] = atan2(Rc[3], Rc[0]);
+        e[2] += 2 * M_PI * round((st[3 + 3 * B + 2] - e[2]) / (2 * M_PI));
+    }
+    /* hooke joints: phi in closed form (cpo_project_dependents handles exactly those when the revolute children are consistent) */
+    for (int j = 0; j < s->n_joints; j++)
+        if (s->joint_kind[j] == CPE_JOINT_HOOKE_YZ) {
+            int p = s->joint_parent[j], ch = s->joint_child[j];
+            double Rp[9]; cpo_rot(st + 3 + 3 * p, Rp);
+            double ax = Rp[1], ay = Rp[4], az = Rp[7];
+            double* ang = st + 3 + 3 * ch;
+            double sth = sin(ang[1]), cth = cos(ang[1]), sp = sin(ang[2]), cp = cos(ang[2]);
+            ang[0] = atan2(ax * sth * cp + ay * sth * sp + az * cth, ay * cp - ax * sp);
+        }
+}
+
+/* state from a (possibly inconsistent) Euler q: alpha_c = angle of R_B^T R_c about y */
+static void state_from_q(const ctx_t* x, const double* q, double* st) {
+    const cpe_skeleton* s = x->s;
+    memcpy(st, q, sizeof(double) * x->nq);
+    for (int r = 0; r < x->nrev; r++) {
+        int c = s->joint_child[x->rev_joint[r]], B = x->rev_body[r];
+        double RB[9], Rc[9];
+        cpo_rot(q + 3 + 3 * B, RB); cpo_rot(q + 3 + 3 * c, Rc);
+        /* M = RB^T Rc ; alpha = atan2(M[0][2], M[0][0]) */
+        double m00 = RB[0] * Rc[0] + RB[3] * Rc[3] + RB[6] * Rc[6], m02 = RB[0] * Rc[2] + RB[3] * Rc[5] + RB[6] * Rc[8];
+        st[x->nq + r] = atan2(m02, m00);
+    }
+    state_sync(x, st);
+}
+
+static void state_add(const ctx_t* x, double* st, int k, double d) {
+    if (x->rev_of_u[k] >= 0) st[x->nq + x->rev_of_u[k]] += d; else st[x->indep[k]] += d;
+}
+
+/* Z' = d(Euler q)/d(u') [nq][nu] by central differences of the explicit map state_sync (the HIP kernels
+ * use the analytic form; the two are independent derivations) */
+static void state_jacobian(const ctx_t* x, const double* st, double* Zp) {
+    const double h = 1e-6;
+    double a[CPE_MAX_NQ + CPE_MAX_JOINTS], b[CPE_MAX_NQ + CPE_MAX_JOINTS];
+    for (int k = 0; k < x->nu; k++) {
+        memcpy(a, st, sizeof(double) * x->ns); memcpy(b, st, sizeof(double) * x->ns);
+        state_add(x, a, k, h); state_add(x, b, k, -h);
+        state_sync(x, a); state_sync(x, b);
+        for (int p = 0; p < x->nq; p++) {
+            double d = a[p] - b[p];
+            if (p >= 3) d = wrap_pi(d);
+            Zp[p * x->nu + k] = d / (2 * h);
+        }
+    }
 }
 
 /* cost terms for one frame; returns meas cost, *cb bound-penalty cost, *cp pose-prior cost */
-static double frame_terms(const ctx_t* x, const double* qn, const double* meas, const double* weight,
+static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* [nq][nu], needed iff g */, const double* meas, const double* weight,
                           const double* mu, double* g, double* Bm, double* cb, double* cp, double* viol_out) {
     const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, L = s->n_markers;
     double pos[CPE_MAX_MARKERS * 3];
-    double* dpos = NULL; double* Z = NULL; double* dpu = NULL;
+    double* dpos = NULL; const double* Z = Zp; double* dpu = NULL;
     int want = g != NULL;
     if (want) {
         dpos = (double*)malloc(sizeof(double) * L * 3 * nq);
-        Z = (double*)malloc(sizeof(double) * nq * nu);
         dpu = (double*)malloc(sizeof(double) * L * 3 * nu);
         cpo_markers_jac(s, qn, pos, dpos);
-        cpo_tangent_basis(s, qn, Z);
         for (int i = 0; i < L * 3; i++)
             for (int k = 0; k < nu; k++) {
                 double a = 0;
@@ -507,10 +600,14 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* meas, 
         double pu = t_up > 0 ? t_up : 0, pl = t_lo > 0 ? t_lo : 0;
         fb += (pu * pu - mu_up * mu_up + pl * pl - mu_lo * mu_lo) / (2 * kp);
         if (want && (pu > 0 || pl > 0)) {
-            int ka = x->u_of_q[ia], kb = ib >= 0 ? x->u_of_q[ib] : -1;
-            double gv = pu - pl, hv = kp * ((pu > 0) + (pl > 0));
-            g[ka] += gv; Bm[ka * nu + ka] += hv;
-            if (kb >= 0) { g[kb] -= gv; Bm[kb * nu + kb] += hv; Bm[ka * nu + kb] -= hv; Bm[kb * nu + ka] -= hv; }
+            /* v is a difference of Euler angles; its gradient w.r.t. the reduced coordinates is a difference of rows of Z' */
+            double gv = pu - pl, hv = kp * ((pu > 0) + (pl > 0)), dv[CPE_NX];
+            for (int k = 0; k < nu; k++) dv[k] = Z[ia * nu + k] - (ib >= 0 ? Z[ib * nu + k] : 0.0);
+            for (int k = 0; k < nu; k++) {
+                if (dv[k] == 0.0) continue;
+                g[k] += gv * dv[k];
+                for (int m = 0; m < nu; m++) Bm[k * nu + m] += hv * dv[k] * dv[m];
+            }
         }
     }
     if (viol_out) *viol_out = vmax;
@@ -522,27 +619,32 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* meas, 
         cpo_relative_angles(s, qn, xr);
         fp = gmm_eval(x->pr, xr + off, want ? gr : NULL, want ? Hx : NULL);
         if (want) {
-            /* x_k = sign_k (u_k - u_ref(k)): chain rule with the sparse +-1 map T (row k: +sign at k, -sign at ref) */
+            /* x_i = sign_i (q_p - q_ref(p)); d x_i / d u' = sign_i (Z'[p] - Z'[ref]) */
+            double Xp[CPE_NX * CPE_NX];
             for (int i = 0; i < D; i++) {
-                int ki = off + i, pi = x->indep[ki];
+                int pi = x->indep[off + i];
                 double si = s->rel_ref[pi] < 0 ? 1.0 : s->rel_sign[pi];
-                int ri = s->rel_ref[pi] < 0 ? -1 : x->u_of_q[s->rel_ref[pi]];
-                g[ki] += si * gr[i]; if (ri >= 0) g[ri] -= si * gr[i];
-                for (int j = 0; j < D; j++) {
-                    int kj = off + j, pj = x->indep[kj];
-                    double sj = s->rel_ref[pj] < 0 ? 1.0 : s->rel_sign[pj];
-                    int rj = s->rel_ref[pj] < 0 ? -1 : x->u_of_q[s->rel_ref[pj]];
-                    double hv = si * sj * Hx[i * D + j];
-                    Bm[ki * nu + kj] += hv;
-                    if (rj >= 0) Bm[ki * nu + rj] -= hv;
-                    if (ri >= 0) Bm[ri * nu + kj] -= hv;
-                    if (ri >= 0 && rj >= 0) Bm[ri * nu + rj] += hv;
-                }
+                for (int k = 0; k < nu; k++) Xp[i * nu + k] = si * (Z[pi * nu + k] - (s->rel_ref[pi] < 0 ? 0.0 : Z[s->rel_ref[pi] * nu + k]));
             }
+            for (int k = 0; k < nu; k++) {
+                double a = 0;
+                for (int i = 0; i < D; i++) a += Xp[i * nu + k] * gr[i];
+                g[k] += a;
+            }
+            for (int i = 0; i < D; i++)
+                for (int j = 0; j < D; j++) {
+                    double hv = Hx[i * D + j];
+                    if (hv == 0.0) continue;
+                    for (int k = 0; k < nu; k++) {
+                        double a = Xp[i * nu + k] * hv;
+                        if (a == 0.0) continue;
+                        for (int m = 0; m < nu; m++) Bm[k * nu + m] += a * Xp[j * nu + m];
+                    }
+                }
         }
     }
     if (cb) *cb = fb; if (cp) *cp = fp;
-    if (want) { free(dpos); free(Z); free(dpu); }
+    if (want) { free(dpos); free(dpu); }
     return fm;
 }
 
@@ -585,18 +687,21 @@ static void band_solve(int n, int kd, const double* ab, double* x) {
  * and, if g != NULL, gradient g[N*nu] and band matrix ab (without damping). */
 typedef struct { double meas, model, pose, motion, bound, total, maxviol; } costs_t;
 
-static void seq_eval(const ctx_t* x, int N, int kd, double* q, const double* meas, const double* weight,
+static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states, synced in place */, const double* meas, const double* weight,
                      const double* mu /* [N][nb][2] or NULL */, costs_t* ct, double* g, double* ab) {
-    const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, L = s->n_markers, C = x->C;
+    const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, ns = x->ns, L = s->n_markers, C = x->C;
     int n_tot = N * nu;
     memset(ct, 0, sizeof(*ct));
     double* gB = g ? (double*)malloc(sizeof(double) * (nu + nu * nu)) : NULL;
+    double* Zall = g ? (double*)malloc(sizeof(double) * (size_t)N * nq * nu) : NULL;   /* Z'_n = d q_n / d u'_n */
     if (g) { memset(g, 0, sizeof(double) * n_tot); memset(ab, 0, sizeof(double) * (size_t)n_tot * (kd + 1)); }
-    int infeasible = 0;
     for (int n = 0; n < N; n++) {
-        infeasible |= cpo_project_dependents(s, q + n * nq);
+        double* sn = st + (size_t)n * ns;
+        state_sync(x, sn);
+        double* Zn = g ? Zall + (size_t)n * nq * nu : NULL;
+        if (g) state_jacobian(x, sn, Zn);
         double cb, cp, vm;
-        double fm = frame_terms(x, q + n * nq, meas + (size_t)n * C * L * 2, weight + (size_t)n * C * L,
+        double fm = frame_terms(x, sn, Zn, meas + (size_t)n * C * L * 2, weight + (size_t)n * C * L,
                                 mu ? mu + (size_t)n * s->n_bounds * 2 : NULL, g ? gB : NULL, g ? gB + nu : NULL, &cb, &cp, &vm);
         ct->meas += fm; ct->bound += cb; ct->pose += cp;
         if (vm > ct->maxviol) ct->maxviol = vm;
@@ -607,75 +712,90 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* q, const double* mea
             }
         }
     }
-    /* constant-acceleration model: sum_{n>=3} w_p eps_{n,p}^2 -- exact quadratic in u */
+#define Q(n, p) st[(size_t)(n) * ns + (p)]
+    /* constant-acceleration model on the EULER angles (acinoset_misc.py:639-677): sum_{n>=3} w_p eps_{n,p}^2,
+     * eps = third difference / h^2; Gauss-Newton through Z' (exactly quadratic for the trunk coordinates) */
     double ih2 = 1.0 / (x->o->h * x->o->h);
     static const double d3[4] = {-1, 3, -3, 1}; /* coefficients of q_{n-3..n} */
     for (int n = 3; n < N; n++)
-        for (int k = 0; k < nu; k++) {
-            int p = x->indep[k]; double w = s->motion_w[p];
+        for (int p = 0; p < nq; p++) {
+            double w = s->motion_w[p];
             if (w == 0) continue;
             double e = 0;
-            for (int t = 0; t < 4; t++) e += d3[t] * q[(n - 3 + t) * nq + p];
+            for (int t = 0; t < 4; t++) e += d3[t] * Q(n - 3 + t, p);
             e *= ih2;
             ct->model += w * e * e;
-            if (g)
-                for (int t = 0; t < 4; t++) {
-                    int it = (n - 3 + t) * nu + k;
-                    g[it] += 2 * w * e * d3[t] * ih2;
-                    for (int t2 = 0; t2 <= t; t2++) AB(it, (n - 3 + t2) * nu + k) += 2 * w * d3[t] * d3[t2] * ih2 * ih2;
+            if (!g) continue;
+            for (int t = 0; t < 4; t++) {
+                const double* Za = Zall + ((size_t)(n - 3 + t) * nq + p) * nu;
+                for (int k = 0; k < nu; k++) {
+                    if (Za[k] == 0.0) continue;
+                    int ia = (n - 3 + t) * nu + k;
+                    g[ia] += 2 * w * e * d3[t] * ih2 * Za[k];
+                    for (int t2 = 0; t2 <= t; t2++) {
+                        const double* Zb = Zall + ((size_t)(n - 3 + t2) * nq + p) * nu;
+                        for (int k2 = 0; k2 < nu; k2++) {
+                            int ib = (n - 3 + t2) * nu + k2;
+                            if (ib > ia || Zb[k2] == 0.0) continue;
+                            AB(ia, ib) += 2 * w * d3[t] * d3[t2] * ih2 * ih2 * Za[k] * Zb[k2];
+                        }
+                    }
                 }
+            }
         }
     /* linear autoregressive motion prior on x (acinoset_misc.py:291-336): for n >= window
-     * slack = x_n - (coef.[x_{n-w};...;x_{n-1}] + b), cost sum_p lr_w[p] slack_p^2 */
+     * slack = x_n - (coef.[x_{n-w};...;x_{n-1}] + b), cost sum_p lr_w[p] slack_p^2 ; x = relative angles of q */
     if (x->pr && x->pr->lr_window > 0) {
         int W = x->pr->lr_window;
         double* xs = (double*)malloc(sizeof(double) * N * nu);
-        for (int n = 0; n < N; n++) cpo_relative_angles(s, q + n * nq, xs + n * nu);
-        /* slack_p = sum_{t=0..W} sum_j K[p][t][j] x_{n-W+t, j} - b_p ; K[.][W] = I, K[.][t<W] = -coef */
-        double* Kx = (double*)malloc(sizeof(double) * nu * (W + 1) * nu);  /* d slack_p / d x */
-        double* Ku = (double*)malloc(sizeof(double) * nu * (W + 1) * nu);  /* d slack_p / d u */
-        for (int p = 0; p < nu; p++)
-            for (int t = 0; t <= W; t++)
-                for (int j = 0; j < nu; j++)
-                    Kx[(p * (W + 1) + t) * nu + j] = t < W ? -x->pr->lr_coef[p][t * nu + j] : (p == j ? 1.0 : 0.0);
-        memset(Ku, 0, sizeof(double) * nu * (W + 1) * nu);
-        for (int p = 0; p < nu; p++)
-            for (int t = 0; t <= W; t++)
-                for (int j = 0; j < nu; j++) {
-                    int pj = x->indep[j]; double v = Kx[(p * (W + 1) + t) * nu + j];
-                    if (v == 0) continue;
-                    if (s->rel_ref[pj] < 0) Ku[(p * (W + 1) + t) * nu + j] += v;
-                    else {
-                        Ku[(p * (W + 1) + t) * nu + j] += s->rel_sign[pj] * v;
-                        Ku[(p * (W + 1) + t) * nu + x->u_of_q[s->rel_ref[pj]]] -= s->rel_sign[pj] * v;
-                    }
+        double* Xp = g ? (double*)malloc(sizeof(double) * (size_t)N * nu * nu) : NULL;     /* d x_n / d u'_n */
+        for (int n = 0; n < N; n++) {
+            cpo_relative_angles(s, st + (size_t)n * ns, xs + n * nu);
+            if (g)
+                for (int i = 0; i < nu; i++) {
+                    int pi = x->indep[i];
+                    double si = s->rel_ref[pi] < 0 ? 1.0 : s->rel_sign[pi];
+                    const double* Za = Zall + ((size_t)n * nq + pi) * nu;
+                    const double* Zr = s->rel_ref[pi] < 0 ? NULL : Zall + ((size_t)n * nq + s->rel_ref[pi]) * nu;
+                    for (int k = 0; k < nu; k++) Xp[((size_t)n * nu + i) * nu + k] = si * (Za[k] - (Zr ? Zr[k] : 0.0));
                 }
+        }
+        double* Ku = g ? (double*)malloc(sizeof(double) * (W + 1) * nu) : NULL;          /* d slack_p / d u'_{n-W+t} */
         for (int n = W; n < N; n++)
             for (int p = 0; p < nu; p++) {
                 double w = x->pr->lr_w[p];
                 if (w == 0) continue;
-                double sl = -x->pr->lr_b[p];
-                for (int t = 0; t <= W; t++) for (int j = 0; j < nu; j++) sl += Kx[(p * (W + 1) + t) * nu + j] * xs[(n - W + t) * nu + j];
+                double sl = xs[n * nu + p] - x->pr->lr_b[p];
+                for (int t = 0; t < W; t++) for (int j = 0; j < nu; j++) sl -= x->pr->lr_coef[p][t * nu + j] * xs[(n - W + t) * nu + j];
                 ct->motion += w * sl * sl;
-                if (g)
-                    for (int t = 0; t <= W; t++) for (int j = 0; j < nu; j++) {
-                        double kj = Ku[(p * (W + 1) + t) * nu + j];
-                        if (kj == 0) continue;
-                        int ia = (n - W + t) * nu + j;
-                        g[ia] += 2 * w * sl * kj;
-                        for (int t2 = 0; t2 <= t; t2++) for (int j2 = 0; j2 < nu; j2++) {
-                            int ib = (n - W + t2) * nu + j2;
-                            if (ib > ia) continue;
-                            double kj2 = Ku[(p * (W + 1) + t2) * nu + j2];
-                            if (kj2 != 0) AB(ia, ib) += 2 * w * kj * kj2;
-                        }
+                if (!g) continue;
+                for (int t = 0; t <= W; t++)
+                    for (int k = 0; k < nu; k++) {
+                        double a = 0;
+                        const double* Xa = Xp + (size_t)(n - W + t) * nu * nu;
+                        if (t == W) a = Xa[p * nu + k];
+                        else for (int j = 0; j < nu; j++) a -= x->pr->lr_coef[p][t * nu + j] * Xa[j * nu + k];
+                        Ku[t * nu + k] = a;
                     }
+                for (int t = 0; t <= W; t++) for (int k = 0; k < nu; k++) {
+                    double kj = Ku[t * nu + k];
+                    if (kj == 0) continue;
+                    int ia = (n - W + t) * nu + k;
+                    g[ia] += 2 * w * sl * kj;
+                    for (int t2 = 0; t2 <= t; t2++) for (int k2 = 0; k2 < nu; k2++) {
+                        int ib = (n - W + t2) * nu + k2;
+                        if (ib > ia) continue;
+                        double kj2 = Ku[t2 * nu + k2];
+                        if (kj2 != 0) AB(ia, ib) += 2 * w * kj * kj2;
+                    }
+                }
             }
-        free(xs); free(Kx); free(Ku);
+        free(xs); if (Xp) free(Xp); if (Ku) free(Ku);
     }
+#undef Q
     ct->total = ct->meas + ct->model + ct->pose + ct->motion + ct->bound;
-    if (infeasible) ct->total = INFINITY; /* joint equalities unsatisfiable at this u: reject the point */
     if (gB) free(gB);
+    if (Zall) free(Zall);
 }
 
 /* Levenberg-Marquardt over the whole trajectory in reduced coordinates (stands where IPOPT is called,
@@ -685,16 +805,16 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
                      const double* weight, double* q, double* dq, double* ddq, double* positions,
                      double* meas_err, cpe_stats* st) {
     ctx_t x; ctx_init(&x, s, cams, C, o, pr);
-    int nq = x.nq, nu = x.nu, L = s->n_markers;
+    int nq = x.nq, nu = x.nu, ns = x.ns, L = s->n_markers;
     int bw = 3; if (pr && pr->lr_window > bw) bw = pr->lr_window;
     int kd = (bw + 1) * nu - 1, n_tot = N * nu;
-    double* qc = (double*)malloc(sizeof(double) * N * nq);
-    double* qt = (double*)malloc(sizeof(double) * N * nq);
+    double* qc = (double*)malloc(sizeof(double) * N * ns);      /* states [N][ns]: Euler q + leg angles */
+    double* qt = (double*)malloc(sizeof(double) * N * ns);
     double* g = (double*)malloc(sizeof(double) * n_tot);
     double* ab = (double*)malloc(sizeof(double) * (size_t)n_tot * (kd + 1));
     double* abf = (double*)malloc(sizeof(double) * (size_t)n_tot * (kd + 1));
     double* dl = (double*)malloc(sizeof(double) * n_tot);
-    memcpy(qc, q_init, sizeof(double) * N * nq);
+    for (int n = 0; n < N; n++) state_from_q(&x, q_init + (size_t)n * nq, qc + (size_t)n * ns);
     costs_t cc, ctr;
     double* mu = (double*)calloc((size_t)N * s->n_bounds * 2 + 1, sizeof(double));
     seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
@@ -722,15 +842,15 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
             if (fabs(dl[i]) > maxstep) maxstep = fabs(dl[i]);
         }
         double pred = -gd - 0.5 * dHd;
-        memcpy(qt, qc, sizeof(double) * N * nq);
-        for (int n = 0; n < N; n++) for (int k = 0; k < nu; k++) qt[n * nq + x.indep[k]] += dl[n * nu + k];
+        memcpy(qt, qc, sizeof(double) * N * ns);
+        for (int n = 0; n < N; n++) for (int k = 0; k < nu; k++) state_add(&x, qt + (size_t)n * ns, k, dl[n * nu + k]);
         seq_eval(&x, N, kd, qt, meas, weight, mu, &ctr, NULL, NULL);
         double act = cc.total - ctr.total;
         double gain = pred > 0 ? act / pred : -1;
         if (getenv("CPO_DEBUG")) fprintf(stderr, "it %3d cost %.10f trial %.10f pred %.3e act %.3e gain %.3f lam %.2e step %.2e viol %.2e\n", it, cc.total, ctr.total, pred, act, gain, lam, maxstep, cc.maxviol);
         if (isfinite(ctr.total) && act > 0 && gain > 1e-4) {
             double rel = act / (fabs(cc.total) + 1e-30);
-            memcpy(qc, qt, sizeof(double) * N * nq);
+            memcpy(qc, qt, sizeof(double) * N * ns);
             seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
             double f = 1 - (2 * gain - 1) * (2 * gain - 1) * (2 * gain - 1);
             lam *= f > 1.0 / 3 ? f : 1.0 / 3; nu_f = 2.0;
@@ -747,7 +867,7 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
                 for (int n = 0; n < N; n++)
                     for (int b = 0; b < s->n_bounds; b++) {
                         int ia = s->bound_a[b], ib = s->bound_b[b];
-                        double v = qc[n * nq + ia] - (ib >= 0 ? qc[n * nq + ib] : 0.0);
+                        double v = qc[(size_t)n * ns + ia] - (ib >= 0 ? qc[(size_t)n * ns + ib] : 0.0);
                         double* m2 = mu + ((size_t)n * s->n_bounds + b) * 2;
                         double t_up = m2[0] + o->bound_penalty * (v - s->bound_up[b]), t_lo = m2[1] + o->bound_penalty * (s->bound_lo[b] - v);
                         m2[0] = t_up > 0 ? t_up : 0; m2[1] = t_lo > 0 ? t_lo : 0;
@@ -759,14 +879,14 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
         }
     }
     /* outputs as CheetahEstimator.save writes them (acinoset_opt.py:289-361) */
-    memcpy(q, qc, sizeof(double) * N * nq);
-    if (dq && ddq) cpo_derivatives(nq, N, o->h, qc, dq, ddq);
+    for (int n = 0; n < N; n++) memcpy(q + (size_t)n * nq, qc + (size_t)n * ns, sizeof(double) * nq);
+    if (dq && ddq) cpo_derivatives(nq, N, o->h, q, dq, ddq);
     double maxc = 0;
     for (int n = 0; n < N; n++) {
         double pos[CPE_MAX_MARKERS * 3], cv[64];
-        cpo_markers(s, qc + n * nq, pos);
+        cpo_markers(s, q + (size_t)n * nq, pos);
         if (positions) memcpy(positions + (size_t)n * L * 3, pos, sizeof(double) * L * 3);
-        int nc = cpo_constraints(s, qc + n * nq, cv, NULL);
+        int nc = cpo_constraints(s, q + (size_t)n * nq, cv, NULL);
         for (int i = 0; i < nc; i++) if (fabs(cv[i]) > maxc) maxc = fabs(cv[i]);
         if (meas_err)
             for (int c = 0; c < C; c++) for (int l = 0; l < L; l++) {
@@ -787,7 +907,7 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
 
 /* reduced gradient / cost at a point (used by tests to check stationarity and by finite-difference checks) */
 double cpo_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
-                     const cpe_priors* pr, int N, double* q /* dependents projected in place */,
+                     const cpe_priors* pr, int N, double* q /* made consistent with the joint equalities in place */,
                      const double* meas, const double* weight, double* g /*[N*nu] or NULL*/,
                      double* Hband /* [N*nu][kd+1] or NULL */, double* terms /*[5] or NULL*/) {
     ctx_t x; ctx_init(&x, s, cams, C, o, pr);
@@ -795,11 +915,43 @@ double cpo_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     int kd = (bw + 1) * x.nu - 1;
     costs_t ct;
     double* ab = NULL;
+    double* st = (double*)malloc(sizeof(double) * (size_t)N * x.ns);
+    for (int n = 0; n < N; n++) state_from_q(&x, q + (size_t)n * x.nq, st + (size_t)n * x.ns);
     if (g) ab = Hband ? Hband : (double*)malloc(sizeof(double) * (size_t)N * x.nu * (kd + 1));
-    seq_eval(&x, N, kd, q, meas, weight, NULL, &ct, g, ab);
+    seq_eval(&x, N, kd, st, meas, weight, NULL, &ct, g, ab);
+    for (int n = 0; n < N; n++) memcpy(q + (size_t)n * x.nq, st + (size_t)n * x.ns, sizeof(double) * x.nq);
     if (g && !Hband) free(ab);
+    free(st);
     if (terms) { terms[0] = ct.meas; terms[1] = ct.model; terms[2] = ct.pose; terms[3] = ct.motion; terms[4] = ct.bound; }
     return ct.total;
+}
+
+/* per-frame terms in reduced coordinates at Euler q_n (made consistent first): measurement + bounds (+ pose prior)
+ * cost[3] = {meas, bound, pose}; g[nu]; B[nu][nu]; Gam[nq][nu] = d Euler / d coordinates (optional) */
+void cpo_frame_normal(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                      double* qn, const double* meas, const double* weight, double* g, double* Bm, double* cost, double* Zout) {
+    ctx_t x; ctx_init(&x, s, cams, C, o, pr);
+    double st[CPE_MAX_NQ + CPE_MAX_JOINTS];
+    state_from_q(&x, qn, st);
+    double* Zp = (double*)malloc(sizeof(double) * x.nq * x.nu);
+    state_jacobian(&x, st, Zp);
+    double cb, cp, vm;
+    cost[0] = frame_terms(&x, st, Zp, meas, weight, NULL, g, Bm, &cb, &cp, &vm);
+    cost[1] = cb; cost[2] = cp;
+    memcpy(qn, st, sizeof(double) * x.nq);
+    if (Zout) memcpy(Zout, Zp, sizeof(double) * x.nq * x.nu);
+    free(Zp);
+}
+
+/* one reduced coordinate of every frame moved by d (tests: finite differences of cpo_objective) */
+void cpo_move_coordinate(const cpe_skeleton* s, int N, double* q, int n, int k, double d) {
+    ctx_t x; ctx_init(&x, s, NULL, 0, NULL, NULL);
+    double st[CPE_MAX_NQ + CPE_MAX_JOINTS];
+    (void)N;
+    state_from_q(&x, q + (size_t)n * x.nq, st);
+    state_add(&x, st, k, d);
+    state_sync(&x, st);
+    memcpy(q + (size_t)n * x.nq, st, sizeof(double) * x.nq);
 }
 
 void cpo_default_options(cpe_options* o) {

@@ -173,3 +173,20 @@ def solve(sk, cams, opts, priors, q_init, meas, weight):
     lib().cpo_solve(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, N,
                     _p(q_init), _p(meas), _p(weight), _p(q), _p(dq), _p(ddq), _p(pos), _p(me), C.byref(st))
     return dict(q=q, dq=dq, ddq=ddq, positions=pos, meas_err=me, stats=st)
+
+
+def move_coordinate(sk, q, n, k, d):
+    """copy of q[N,nq] with reduced coordinate k of frame n moved by d (leg coordinates are the rotation
+    angles alpha_c about the body's y axis, trunk coordinates are Euler angles / translations)"""
+    q = _c(q).copy()
+    lib().cpo_move_coordinate(C.byref(sk), q.shape[0], _p(q), int(n), int(k), C.c_double(d))
+    return q
+
+
+def frame_normal(sk, cams, opts, priors, q, meas, weight):
+    """per-frame reduced gradient g[nu], Gauss-Newton block B[nu,nu], cost[3] and Z' = d Euler/d coordinates"""
+    q = _c(q).copy(); meas = _c(meas); weight = _c(weight)
+    g = np.empty(abi.NX); Bm = np.empty((abi.NX, abi.NX)); cost = np.empty(3); Z = np.empty((sk.nq, abi.NX))
+    lib().cpo_frame_normal(C.byref(sk), cams, weight.shape[0], C.byref(opts), C.byref(priors) if priors is not None else None,
+                           _p(q), _p(meas), _p(weight), _p(g), _p(Bm), _p(cost), _p(Z))
+    return g, Bm, cost, Z, q

@@ -182,3 +182,63 @@ def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_
     meas = np.ascontiguousarray(Z["uv"][None])
     r, J, eps, cost = h.eval_resjac_host(q, meas, np.ones((1, 57, 6, 24)))
     assert np.abs(r).max() < 1e-4 and np.sqrt((r ** 2).mean()) < 5e-6
+
+
+def test_frame_normal_matches_oracle(sk25, cams6, oracle, gpu_handle_factory):
+    """per-frame reduced gradient, Gauss-Newton block and d(leg pitch)/d(coordinates) of the HIP kernel against
+    the oracle (which differentiates the explicit coordinate map numerically) -- including limbs pitched beyond
+    90 degrees under a rolled body, where the absolute-Euler pitch turns back (both cos(phi) branches)."""
+    import torch
+    h = gpu_handle_factory(sk25, cams6)
+    d = synth.make_batch(sk25, cams6, B=2, N=6, seed=41)
+    rng = np.random.default_rng(8)
+    q = d["q_true"] + rng.normal(0, 0.02, d["q_true"].shape)
+    q[..., 3] += 0.25                                            # roll the base: a_z != 0
+    for lk in ("HFL", "LBR", "LFR", "UBL"):
+        q[..., skeleton.dof(lk, 1)] += rng.uniform(1.2, 2.2)     # swing some limbs far beyond 90 degrees
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    g = torch.empty((2, 6, 28), dtype=torch.float64, device=dev); Bm = torch.empty((2, 6, 28, 28), dtype=torch.float64, device=dev)
+    cost = torch.empty((2, 6, 2), dtype=torch.float64, device=dev); gam = torch.empty((2, 6, 12, 4), dtype=torch.float64, device=dev)
+    qo = torch.empty((2, 6, sk25.nq), dtype=torch.float64, device=dev)
+    h.eval_normal(T(q), T(d["meas"]), T(d["weight"]), g, Bm, cost, gam, qo); h.synchronize()
+    g, Bm, cost, gam, qo = (x.cpu().numpy() for x in (g, Bm, cost, gam, qo))
+    opts = abi.default_options()
+    ind = list(skeleton.independent_dofs(sk25))
+    legs = [(sk25.joint_child[j], sk25.joint_parent[j]) for j in range(sk25.n_joints) if sk25.joint_kind[j] == 0]
+    saw_other_branch = False
+    for b in range(2):
+        for n in range(6):
+            go, Bo, co, Z, qc = oracle.frame_normal(sk25, cams6, opts, None, q[b, n], d["meas"][b, n], d["weight"][b, n])
+            assert np.abs(qo[b, n] - qc).max() < 1e-11
+            assert np.abs(oracle.constraints(sk25, qo[b, n])).max() < 1e-12
+            saw_other_branch |= bool((np.abs(qc[3::3][1:]) > np.pi / 2).any())          # some |phi_c| > 90 deg
+            assert abs(cost[b, n, 0] - co[0]) < 1e-9 * abs(co[0]) and abs(cost[b, n, 1] - co[1]) < 1e-9 * max(1.0, abs(co[1]))
+            assert np.abs(g[b, n] - go).max() < 2e-6 * max(1.0, np.abs(go).max())
+            assert np.abs(Bm[b, n] - Bo).max() < 2e-6 * np.abs(Bo).max()
+            for r, (c, _) in enumerate(legs):
+                body = 1 if skeleton.LINKS[c][1] == "F" else 0
+                cols = [ind.index(3 + 3 * c + 1)] + [ind.index(3 + 3 * body + a) for a in range(3)]
+                assert np.abs(gam[b, n, r] - Z[3 + 3 * c + 1, cols]).max() < 1e-7
+    assert saw_other_branch
+
+
+def test_solve_through_the_gimbal_region(cams6, oracle, gpu_handle_factory):
+    """limbs swinging beyond 90 degrees of pitch under a rolled trunk (both cos(phi) branches of the joint
+    equalities, as in the stored AcinoSet runs): HIP and oracle follow the same path in the leg-angle coordinates."""
+    sk = skeleton.build_skeleton("phantom", 25)
+    sk.n_bounds = 0
+    opts = abi.default_options()
+    h = gpu_handle_factory(sk, cams6, opts)
+    d = synth.make_batch(sk, cams6, B=2, N=24, seed=61, wide_limbs=True)
+    out = h.solve_host(d["q_init"], d["meas"], d["weight"])
+    seen = 0
+    for b in range(2):
+        ref = oracle.solve(sk, cams6, opts, None, d["q_init"][b], d["meas"][b], d["weight"][b])
+        assert out["stats"][b].status == abi.OK and ref["stats"].status == abi.OK
+        rmse = np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean())
+        assert rmse < 1e-4, rmse
+        c = np.array([np.abs(oracle.constraints(sk, x)).max() for x in out["q"][b]])
+        assert c.max() < 1e-12
+        seen += int((np.abs(out["q"][b][:, 3::3][:, 5:]) > np.pi / 2).sum())
+    assert seen > 10

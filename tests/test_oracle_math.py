@@ -98,9 +98,8 @@ def test_reduced_gradient_fd_and_band_matrix(oracle, sk25, cams6):
     rng = np.random.default_rng(4)
     for _ in range(12):
         n, k = rng.integers(0, 8), rng.integers(0, abi.NX)
-        e = np.zeros_like(qproj); e[n, indep[k]] = 1e-6
-        fp = oracle.objective(sk25, cams6, opts, None, qproj + e, d["meas"][0], d["weight"][0])[0]
-        fm = oracle.objective(sk25, cams6, opts, None, qproj - e, d["meas"][0], d["weight"][0])[0]
+        fp = oracle.objective(sk25, cams6, opts, None, oracle.move_coordinate(sk25, qproj, n, k, 1e-6), d["meas"][0], d["weight"][0])[0]
+        fm = oracle.objective(sk25, cams6, opts, None, oracle.move_coordinate(sk25, qproj, n, k, -1e-6), d["meas"][0], d["weight"][0])[0]
         fd = (fp - fm) / 2e-6
         assert abs(fd - g[n * abi.NX + k]) < 1e-5 * max(1.0, abs(fd))
     # band matrix is symmetric positive semidefinite with half-bandwidth 3 blocks
@@ -145,3 +144,21 @@ def test_oracle_solver_converges_to_stationary_point(oracle, sk25, cams6):
     truth = oracle.markers(sk25, d["q_true"][0])
     assert np.sqrt(((res["positions"] - truth) ** 2).sum(-1).mean()) < 0.05      # 2 px noise -> centimetres
     assert res["stats"].max_constraint < 1e-13
+
+
+def test_oracle_solver_through_the_gimbal_region(oracle, sk25, cams6):
+    """Limbs pitched beyond 90 degrees under a rolled trunk: the absolute-Euler pitch of the reference's model turns
+    back and phi/psi swing by ~180 deg (29 of 798 link states of the stored run 2019_03_07/phantom are like that).
+    The leg-angle coordinates alpha carry the solver through; the result satisfies all 26 joint equalities."""
+    sk25 = skeleton.build_skeleton("phantom", 25)
+    sk25.n_bounds = 0            # the exaggerated swing leaves the reference's joint ranges; bounds have their own test
+    d = synth.make_batch(sk25, cams6, B=1, N=24, seed=61, wide_limbs=True)
+    qt = d["q_true"][0]
+    assert np.abs(np.array([oracle.constraints(sk25, x) for x in qt])).max() < 1e-12
+    phis = qt[:, 3::3][:, 5:]
+    assert (np.abs(phis) > np.pi / 2).sum() > 10                       # the other cos(phi) branch really occurs
+    opts = abi.default_options()
+    res = oracle.solve(sk25, cams6, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+    assert res["stats"].status == abi.OK and res["stats"].max_constraint < 1e-12
+    truth = oracle.markers(sk25, qt)
+    assert np.sqrt(((res["positions"] - truth) ** 2).sum(-1).mean()) < 0.05
