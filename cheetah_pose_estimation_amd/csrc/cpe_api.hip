@@ -163,6 +163,8 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             }
         }
     m.ns = nq + m.nrev;
+    if (m.nrev > LM_MAX_REV) return fail(CPE_BAD_ARG, "more than 12 leg links");
+    for (int k = 0; k < nu; k++) if (m.bodyang_legs_n[k] > LM_MAX_LEGS) return fail(CPE_BAD_ARG, "more than 6 leg links on one body");
     for (int r = 0; r < m.nrev; r++) m.ucoord_src[m.rev_u[r]] = nq + r;
     m.n_trunk = 0;
     for (int i = 0; i < nl; i++) if (rev_of_link[i] < 0) m.trunk_link[m.n_trunk++] = i;
@@ -465,7 +467,7 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     LmParams prm;
     prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
-    prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.pad = 0;
+    prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;
     const size_t ldsn = lds_normal(m);
     hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf);
     hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 1, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf);
@@ -491,7 +493,7 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     cpe_status worst = CPE_OK;
     for (int b = 0; b < B; b++) {
         const SeqState& S = hs[b];
-        const cpe_status sb = S.status == 1 ? CPE_OK : (S.status == 0 ? CPE_MAX_ITER : CPE_NUMERICAL);
+        const cpe_status sb = S.status == 1 ? CPE_OK : ((S.status == 0 || S.status == 3) ? CPE_MAX_ITER : CPE_NUMERICAL);
         if (sb > worst) worst = sb;
         if (stats) {
             cpe_stats& o = stats[b];

@@ -104,7 +104,7 @@ struct DevModel {
 // per-sequence Levenberg-Marquardt state (device global memory)
 struct SeqState {
     int32_t cur;        // which of the two buffers holds the current iterate
-    int32_t status;     // 0 running, 1 converged, 2 numerical failure
+    int32_t status;     // 0 running, 1 converged, 2 numerical failure, 3 iteration limit
     int32_t iters;
     int32_t rejects;
     int32_t outer;      // augmented-Lagrangian multiplier updates done

@@ -225,19 +225,25 @@ def test_frame_normal_matches_oracle(sk25, cams6, oracle, gpu_handle_factory):
 
 def test_solve_through_the_gimbal_region(cams6, oracle, gpu_handle_factory):
     """limbs swinging beyond 90 degrees of pitch under a rolled trunk (both cos(phi) branches of the joint
-    equalities, as in the stored AcinoSet runs): HIP and oracle follow the same path in the leg-angle coordinates."""
+    equalities, as in the stored AcinoSet runs).  From a start near the truth HIP and oracle follow the same path in the
+    leg-angle coordinates and agree to fp64 round-off amplified by ~50 LM iterations.  (From the zero-angle initial
+    guess such an exaggerated swing is a hard non-convex problem whose early path is chaotic -- two runs of the same
+    algorithm with 1e-10 different Jacobians may settle in neighbouring minima -- so that case is not a parity test;
+    tests/test_oracle_math.py covers convergence from the far start on the CPU.)"""
     sk = skeleton.build_skeleton("phantom", 25)
     sk.n_bounds = 0
     opts = abi.default_options()
     h = gpu_handle_factory(sk, cams6, opts)
     d = synth.make_batch(sk, cams6, B=2, N=24, seed=61, wide_limbs=True)
-    out = h.solve_host(d["q_init"], d["meas"], d["weight"])
+    near = d["q_true"] + np.random.default_rng(0).normal(0, 0.01, d["q_true"].shape)
+    out = h.solve_host(near, d["meas"], d["weight"])
     seen = 0
     for b in range(2):
-        ref = oracle.solve(sk, cams6, opts, None, d["q_init"][b], d["meas"][b], d["weight"][b])
+        ref = oracle.solve(sk, cams6, opts, None, near[b], d["meas"][b], d["weight"][b])
         assert out["stats"][b].status == abi.OK and ref["stats"].status == abi.OK
         rmse = np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean())
         assert rmse < 1e-4, rmse
+        assert abs(out["stats"][b].cost - ref["stats"].cost) < 1e-7 * abs(ref["stats"].cost)
         c = np.array([np.abs(oracle.constraints(sk, x)).max() for x in out["q"][b]])
         assert c.max() < 1e-12
         seen += int((np.abs(out["q"][b][:, 3::3][:, 5:]) > np.pi / 2).sum())
