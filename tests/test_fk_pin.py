@@ -71,3 +71,35 @@ def test_numpy_host_fk_agrees_on_the_recovered_angles():
     for c in range(6):
         uv, _ = synth.project_numpy(cams[c], pos)
         assert np.abs(uv - Z["uv"][:, c]).max() < 1e-4
+
+
+def real_run_problem(noise_px=2.0, drop=0.4, outliers=0.05, init_noise=0.05, seed=0):
+    """An estimation problem on REAL cheetah motion: the 57-frame trajectory and the 6 cameras recovered from the
+    reference's stored run, its own reprojections as measurements plus DLC-like noise, drop-outs and outliers, and
+    a perturbed start.  Limb links swing beyond the horizontal under a rolled trunk in this run."""
+    sk = skeleton.build_skeleton(str(Z["animal"]), 24)
+    q, uv = Z["q"], Z["uv"]
+    N = q.shape[0]
+    rng = np.random.default_rng(seed)
+    meas = uv + rng.normal(0, noise_px, uv.shape)
+    weight = np.broadcast_to(1.0 / skeleton.measurement_sigma(24, False), (N, 6, 24)).copy()
+    weight[rng.random((N, 6, 24)) < drop] = 0.0
+    out = rng.random((N, 6, 24)) < outliers
+    meas[out] += rng.normal(0, 200, (out.sum(), 2))
+    ind = skeleton.independent_dofs(sk)
+    q_init = q.copy()
+    q_init[:, ind] += rng.normal(0, init_noise, (N, len(ind)))
+    return sk, _cams(), q_init, np.ascontiguousarray(meas), weight, q
+
+
+def test_oracle_solver_on_the_real_run(oracle):
+    """2 px noise, 40 % drop-outs, 5 % gross outliers on real motion: the solve converges, keeps the joint ranges and
+    lands within millimetres of the reference's own stored solution."""
+    sk, cams, q_init, meas, weight, q_ref = real_run_problem()
+    opts = abi.default_options(90.0)
+    res = oracle.solve(sk, cams, opts, None, q_init, meas, weight)
+    st = res["stats"]
+    assert st.status == abi.OK and st.iterations < 60
+    assert st.max_bound_violation < 1e-5 and st.max_constraint < 1e-12
+    err = np.sqrt(((res["positions"] - oracle.markers(sk, q_ref)) ** 2).sum(-1))
+    assert np.sqrt((err ** 2).mean()) < 0.008 and err.max() < 0.04

@@ -184,6 +184,25 @@ def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_
     assert np.abs(r).max() < 1e-4 and np.sqrt((r ** 2).mean()) < 5e-6
 
 
+def test_solve_on_the_real_run_matches_oracle(oracle, gpu_handle_factory):
+    """Real cheetah motion (the reference's stored run, limbs beyond the horizontal under a rolled trunk, active joint
+    ranges): HIP solver vs oracle on identical noisy inputs, 1 mm bar."""
+    from test_fk_pin import real_run_problem
+    sk, cams, q_init, meas, weight, q_ref = real_run_problem()
+    opts = abi.default_options(90.0)
+    h = gpu_handle_factory(sk, cams, opts)
+    out = h.solve_host(q_init[None], meas[None], weight[None])
+    ref = oracle.solve(sk, cams, opts, None, q_init, meas, weight)
+    st = out["stats"][0]
+    assert st.status == abi.OK and ref["stats"].status == abi.OK
+    rmse = np.sqrt(((out["positions"][0] - ref["positions"]) ** 2).sum(-1).mean())
+    assert rmse < 1e-3, rmse
+    assert abs(st.cost - ref["stats"].cost) < 1e-5 * abs(ref["stats"].cost)
+    assert st.max_bound_violation < 1e-5
+    err = np.sqrt(((out["positions"][0] - oracle.markers(sk, q_ref)) ** 2).sum(-1))
+    assert np.sqrt((err ** 2).mean()) < 0.008
+
+
 def test_frame_normal_matches_oracle(sk25, cams6, oracle, gpu_handle_factory):
     """per-frame reduced gradient, Gauss-Newton block and d(leg pitch)/d(coordinates) of the HIP kernel against
     the oracle (which differentiates the explicit coordinate map numerically) -- including limbs pitched beyond
