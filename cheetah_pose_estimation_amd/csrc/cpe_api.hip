@@ -32,6 +32,11 @@ struct cpe_handle {
            *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr, *gambuf = nullptr;
     SeqState* st = nullptr;
     int* flag = nullptr;
+    // learned priors (config 3)
+    DevPriors* pri = nullptr;    // device copy, nullptr without priors
+    int gmm_k = 0, gmm_dim = 0, lr_window = 0;
+    double* Hlr = nullptr;       // [2][F][pb][nu*nu] off-diagonal Gauss-Newton blocks of the autoregressive prior
+    int pb = 3;                  // half-bandwidth of the normal equations in frames (4 with a window-4 motion prior)
 };
 
 static double host_rho0(double a, double b, double c) {
@@ -269,9 +274,11 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
 }
 
 static size_t lds_fk(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C); }
-static size_t lds_normal(const DevModel& m) {
-    return sizeof(double) * (m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.nl + 3 * m.L + 23 * m.C + 3 * m.sv_n + GAM_STRIDE * m.nrev + 3 * m.ss_n +
-                             CPE_MAX_SCOL * m.ndep + 9 * m.L + 3 * m.mc_total + m.nu * m.nu + m.nu);
+static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0) {
+    size_t n = m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.nl + 3 * m.L + 23 * m.C + 3 * m.sv_n + GAM_STRIDE * m.nrev + 3 * m.ss_n +
+               CPE_MAX_SCOL * m.ndep + 9 * m.L + 3 * m.mc_total + m.nu * m.nu + m.nu;
+    if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX + gmm_dim * gmm_dim + 2 * gmm_dim * m.nu;
+    return sizeof(double) * n;
 }
 
 extern "C" {
@@ -287,7 +294,12 @@ void cpe_default_options(cpe_options* o) {
 cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts,
                       const cpe_priors* priors, int32_t device, cpe_handle** out) {
     if (!skel || !cams || !opts || !out) return fail(CPE_BAD_ARG, "null argument");
-    if (priors && (priors->gmm_k > 0 || priors->lr_window > 0)) return fail(CPE_BAD_ARG, "learned priors are not implemented in this build");
+    const bool use_pri = priors && (priors->gmm_k > 0 || priors->lr_window > 0);
+    if (use_pri) {
+        if (priors->gmm_k < 0 || priors->gmm_k > CPE_MAX_GMM || priors->gmm_dim < 0 || priors->gmm_dim > CPE_NX || (priors->gmm_k > 0 && priors->gmm_dim < 1))
+            return fail(CPE_BAD_ARG, "pose prior: component count / dimension out of range");
+        if (priors->lr_window < 0 || priors->lr_window > CPE_MAX_WINDOW) return fail(CPE_BAD_ARG, "motion prior: window out of range");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CPE_NO_DEVICE, "no HIP device: this library has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(CPE_BAD_ARG, "device index out of range");
@@ -310,14 +322,42 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
     HIPCHK(hipMalloc(&h->dm, sizeof(DevModel)));
     HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&h->flag, sizeof(int)));
+    if (use_pri) {
+        if (h->hm.nu != CPE_NX) return fail(CPE_BAD_ARG, "learned priors need the 28 relative angles of the reference's skeleton");
+        if (priors->gmm_k > 0 && priors->gmm_dim > h->hm.nu) return fail(CPE_BAD_ARG, "pose prior dimension exceeds the number of relative angles");
+        std::vector<DevPriors> hp(1);
+        DevPriors& P = hp[0];
+        memset(&P, 0, sizeof(P));
+        P.p = *priors;
+        const int W = priors->lr_window, nu = CPE_NX;
+        if (W > 0) {
+            // K_t[p][j]: lag blocks of slack = sum_t K_t x_{n-W+t} - b
+            auto K = [&](int t, int p2, int j) -> double { return t == W ? (p2 == j ? 1.0 : 0.0) : -priors->lr_coef[p2][t * nu + j]; };
+            for (int ta = 0; ta <= W; ta++)
+                for (int tb = 0; tb <= ta; tb++)
+                    for (int i = 0; i < nu; i++)
+                        for (int j = 0; j < nu; j++) {
+                            double a = 0.0;
+                            for (int p2 = 0; p2 < nu; p2++) a += K(ta, p2, i) * priors->lr_w[p2] * K(tb, p2, j);
+                            P.lr_PK[ta][tb][i * nu + j] = 2.0 * a;
+                        }
+            for (int k = 0; k <= W; k++)
+                for (int ta = k; ta <= W; ta++)
+                    for (int e = 0; e < nu * nu; e++) P.lr_HI[k][e] += P.lr_PK[ta][ta - k][e];
+        }
+        HIPCHK(hipMalloc(&h->pri, sizeof(DevPriors)));
+        HIPCHK(hipMemcpy(h->pri, &P, sizeof(DevPriors), hipMemcpyHostToDevice));
+        h->gmm_k = priors->gmm_k; h->gmm_dim = priors->gmm_dim; h->lr_window = W;
+        h->pb = W > 3 ? W : 3;
+    }
     *out = h;
     return CPE_OK;
 }
 
 static void free_ws(cpe_handle* h) {
-    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st};
+    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st, h->Hlr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = nullptr; h->st = nullptr;
+    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = h->Hlr = nullptr; h->st = nullptr;
     h->ws_frames = 0; h->ws_B = 0;
 }
 
@@ -327,6 +367,7 @@ void cpe_destroy(cpe_handle* h) {
     free_ws(h);
     if (h->dm) (void)hipFree(h->dm);
     if (h->flag) (void)hipFree(h->flag);
+    if (h->pri) (void)hipFree(h->pri);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -417,11 +458,12 @@ static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     HIPCHK(hipMalloc(&h->Bbuf, sizeof(double) * 2 * F * nu * nu));
     HIPCHK(hipMalloc(&h->costbuf, sizeof(double) * 2 * F * COST_STRIDE));
     HIPCHK(hipMalloc(&h->mu, sizeof(double) * (F * (size_t)(h->hm.nb > 0 ? h->hm.nb : 1) * 2)));
-    HIPCHK(hipMalloc(&h->Lbuf, sizeof(double) * F * 4 * nu * nu));
+    HIPCHK(hipMalloc(&h->Lbuf, sizeof(double) * F * (h->pb + 1) * nu * nu));
     HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * F * nu));
     HIPCHK(hipMalloc(&h->gtbuf, sizeof(double) * F * nu));
     HIPCHK(hipMalloc(&h->cmax, sizeof(double) * F));
     HIPCHK(hipMalloc(&h->st, sizeof(SeqState) * B));
+    if (h->lr_window > 0) HIPCHK(hipMalloc(&h->Hlr, sizeof(double) * 2 * F * h->pb * nu * nu));
     h->ws_frames = F; h->ws_B = B;
     return CPE_OK;
 }
@@ -440,8 +482,8 @@ cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q,
     hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q, h->qbuf);
     HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
-    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
-                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf);
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
     HIPCHK(hipMemcpyAsync(g, h->gbuf, sizeof(double) * F * m.nu, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(Bm, h->Bbuf, sizeof(double) * F * m.nu * m.nu, hipMemcpyDeviceToDevice, h->stream));
     hipLaunchKernelGGL(k_gather_normal, dim3((unsigned)F), dim3(128), 0, h->stream, h->dm, F, h->qbuf, h->costbuf, h->gambuf, cost, gam, q_out);
@@ -468,15 +510,22 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     LmParams prm;
     prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
     prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;
-    const size_t ldsn = lds_normal(m);
-    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf);
-    hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 1, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf);
+    const size_t ldsn = lds_normal(m, h->gmm_k, h->gmm_dim);
+    const bool lr = h->lr_window > 0;
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
+    if (lr) hipLaunchKernelGGL(k_lr_band, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf, h->Hlr, h->costbuf);
+    auto lm_step = [&](int first) {
+        if (h->pb == 3) hipLaunchKernelGGL(k_lm_step<3>, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr);
+        else hipLaunchKernelGGL(k_lm_step<4>, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr);
+    };
+    lm_step(1);
     HIPCHK(hipGetLastError());
     std::vector<SeqState> hs(B);
     const int rounds = h->opts.max_iter + 2 * (h->opts.max_outer > 0 ? h->opts.max_outer : 0);   // a multiplier update costs one extra round
     for (int it = 0; it < rounds; it++) {
-        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf);
-        hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, 0, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf);
+        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
+        if (lr) hipLaunchKernelGGL(k_lr_band, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf, h->Hlr, h->costbuf);
+        lm_step(0);
         if ((it & 7) == 7 || it == rounds - 1) {
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));

@@ -101,6 +101,16 @@ struct DevModel {
     double ss_vec[CPE_MAX_SLOTS][3];
 };
 
+// learned priors (config 3) in device memory: the ABI struct plus host-precomputed x-space Gauss-Newton blocks of the
+// autoregressive prior, slack_n = sum_{t=0..W} K_t x_{n-W+t} - b with K_W = I, K_t = -coef[:, t] (acinoset_misc.py:291-336):
+// lr_PK[ta][tb] = 2 K_ta^T diag(w) K_tb for ta >= tb (frame distance ta - tb);
+// lr_HI[k] = sum_ta lr_PK[ta][ta-k]: the block at frame distance k for a frame away from the sequence ends.
+struct DevPriors {
+    cpe_priors p;
+    double lr_PK[CPE_MAX_WINDOW + 1][CPE_MAX_WINDOW + 1][CPE_NX * CPE_NX];
+    double lr_HI[CPE_MAX_WINDOW + 1][CPE_NX * CPE_NX];
+};
+
 // per-sequence Levenberg-Marquardt state (device global memory)
 struct SeqState {
     int32_t cur;        // which of the two buffers holds the current iterate

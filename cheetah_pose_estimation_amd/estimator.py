@@ -367,9 +367,15 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
     """Same signature as acinoset_opt.estimate_kinematics (acinoset_opt.py:539-547) plus two optional
     keyword arguments.  Returns True when the solve converged (IPOPT `ok`+`optimal` in the reference)."""
     est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
+    pri = None
     if monocular_constraints and scene.cam_idx is not None and not (disable_pose_prior and disable_motion_prior):
-        raise NotImplementedError("learned pose / motion priors on the GPU are SURVEY 8 rows a10/a11 (next); "
-                                  "pass disable_pose_prior=True, disable_motion_prior=True")
+        # acinoset_opt.py:593-600.  The fitted numbers ship as package data (tools/fit_priors.py re-runs the reference's
+        # recipe: 5-component GMM, window-4 multi-task lasso); other sizes would need a refit.
+        if (not disable_pose_prior and pose_model_num_components != 5) or \
+                (not disable_motion_prior and (motion_model_window_size != 4 or not motion_model_sparse_solution)):
+            raise NotImplementedError("only the reference's defaults (5 GMM components, sparse window-4 motion model) are packaged")
+        from . import priors as _priors
+        pri = _priors.load_priors(pose=not disable_pose_prior, motion=not disable_motion_prior)
     N = params.end_frame - params.start_frame
     if q_init is None:
         base_len = 2.0 * abs(sk.marker_off[5][0])
@@ -381,7 +387,7 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
             q_init[:, 3 + 3 * i + 2] = psi[sl]
     opts = options if options is not None else abi.default_options(scene.fps)
     opts.h = 1.0 / scene.fps
-    h = _lib.Handle(sk, est.cams, opts, device=est.device)
+    h = _lib.Handle(sk, est.cams, opts, pri, device=est.device)
     try:
         t0 = time()
         res = h.solve_host(q_init[None], est.meas[None], est.weight[None])
@@ -399,7 +405,7 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
     est.result = res
     est.costs = {"measurement": st.cost_meas, "model": st.cost_model, "pose": st.cost_pose, "motion": st.cost_motion}
     if solver_output:
-        print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- model: {st.cost_model}\n"
+        print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- model: {st.cost_model}\n-- pose: {st.cost_pose}\n-- motion: {st.cost_motion}\n"
               f"status {st.status}, {st.iterations} LM iterations, {est.opt_time_s:.3f} s")
     ok = st.status == abi.OK
     if ok:

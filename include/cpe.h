@@ -175,8 +175,8 @@ cpe_status cpe_project_joints(cpe_handle* h, int32_t B, int32_t N, double* q);
 
 /* ---- building block of the solver: per-frame terms in the reduced coordinates at the Euler
  * iterate q (leg angles are taken as rotations of their body about its y axis, tails re-projected).
- * Device pointers.  g [B][N][28]; Bm [B][N][28][28] (measurement + bound Gauss-Newton block);
- * cost [B][N][2] = {robust measurement cost, bound term}; gam [B][N][nrev][4] = d theta_leg / d(alpha, phi_B, theta_B, psi_B);
+ * Device pointers.  g [B][N][28]; Bm [B][N][28][28] (measurement + bound + pose-prior Gauss-Newton block);
+ * cost [B][N][3] = {robust measurement cost, bound term, pose-prior term}; gam [B][N][nrev][4] = d theta_leg / d(alpha, phi_B, theta_B, psi_B);
  * q_out [B][N][nq] = the consistent Euler angles.  gam and q_out may be NULL. */
 cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
                            double* g, double* Bm, double* cost, double* gam, double* q_out);

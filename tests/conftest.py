@@ -45,8 +45,8 @@ def gpu_handle_factory():
     from cheetah_pose_estimation_amd import _lib
     made = []
 
-    def make(sk, cams, opts=None):
-        h = _lib.Handle(sk, cams, opts)
+    def make(sk, cams, opts=None, priors=None):
+        h = _lib.Handle(sk, cams, opts, priors)
         made.append(h)
         return h
     yield make
