@@ -172,7 +172,7 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
     for (int k = 0; k < nu; k++) if (m.bodyang_legs_n[k] > LM_MAX_LEGS) return fail(CPE_BAD_ARG, "more than 6 leg links on one body");
     for (int r = 0; r < m.nrev; r++) m.ucoord_src[m.rev_u[r]] = nq + r;
     m.n_trunk = 0;
-    for (int i = 0; i < nl; i++) if (rev_of_link[i] < 0) m.trunk_link[m.n_trunk++] = i;
+    for (int i = 0; i < nl; i++) { m.trunk_slot[i] = -1; if (rev_of_link[i] < 0) { m.trunk_slot[i] = m.n_trunk; m.trunk_link[m.n_trunk++] = i; } }
     // marker chains and Jacobian slots
     int S = 0, mct = 0, ss = 0, sv = 0;
     for (int l = 0; l < L; l++) {
@@ -224,7 +224,7 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             m.pc_link[l][i] = link;
             for (int d = 0; d < 3; d++) m.pc_vec[l][i][d] = m.chain_vec[l][i][d];
             for (int a = 0; a < 3 && ok; a++) {
-                const int sl = new_slot(9 * (4 * link + 1 + a), -1, m.chain_vec[l][i]);
+                const int sl = new_slot(9 * (4 * m.trunk_slot[link] + 1 + a), -1, m.chain_vec[l][i]);
                 const int p = 3 + 3 * link + a;
                 if (sl < 0) { ok = false; break; }
                 if (m.u_of_q[p] >= 0) ok = add_term(m.u_of_q[p], sl, -1);
@@ -245,14 +245,14 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             }
             m.pw_id[l] = wid; m.pw_body[l] = Bk;
             for (int a = 0; a < 3 && ok; a++) {           // body angles act on the whole leg vector
-                const int sl = new_slot(9 * (4 * Bk + 1 + a), wid, nullptr);
+                const int sl = new_slot(9 * (4 * m.trunk_slot[Bk] + 1 + a), wid, nullptr);
                 ok = sl >= 0 && add_term(m.u_of_q[3 + 3 * Bk + a], sl, -1);
             }
             for (int i = 0; i < nleg && ok; i++) {        // alpha of each leg link
                 const int did = sv++;
                 m.sv_kind[did] = 1; m.sv_cnt[did] = 1; m.sv_rev[did][0] = m.sv_rev[wid][i];
                 for (int d = 0; d < 3; d++) m.sv_vec[did][0][d] = m.sv_vec[wid][i][d];
-                const int sl = new_slot(9 * (4 * Bk), did, nullptr);
+                const int sl = new_slot(9 * (4 * m.trunk_slot[Bk]), did, nullptr);
                 ok = sl >= 0 && add_term(m.rev_u[m.sv_rev[wid][i]], sl, -1);
             }
         }
@@ -275,8 +275,10 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
 
 static size_t lds_fk(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C); }
 static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0) {
-    size_t n = m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.nl + 3 * m.L + 23 * m.C + 3 * m.sv_n + GAM_STRIDE * m.nrev + 3 * m.ss_n +
-               CPE_MAX_SCOL * m.ndep + 9 * m.L + 3 * m.mc_total + m.nu * m.nu + m.nu;
+    // H | g overlay the solver-slot vectors dp and the S rows (dead once Dp is built): the larger of the two
+    size_t ov = 3 * m.ss_n + CPE_MAX_SCOL * m.ndep, hg = m.nu * m.nu + m.nu;
+    size_t n = m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.n_trunk + 3 * m.L + 3 * m.sv_n + GAM_STRIDE * m.nrev + (ov > hg ? ov : hg) +
+               9 * m.L + 3 * m.mc_total;
     if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX + gmm_dim * gmm_dim + 2 * gmm_dim * m.nu;
     return sizeof(double) * n;
 }
@@ -556,6 +558,16 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
 }
 
 #ifdef CPE_LM_STAMPS
+// diagnostic build only: table sizes and LDS bytes of the per-frame kernels for a model (needs no GPU)
+cpe_status cpe_debug_footprint(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts, int64_t* out16) {
+    std::vector<DevModel> mv(1);
+    cpe_status s = build_model(skel, cams, n_cams, opts, mv[0]);
+    if (s != CPE_OK) return s;
+    const DevModel& m = mv[0];
+    const int64_t v[16] = {m.nq, m.ns, m.nu, m.ndep, m.nrev, m.S, m.ss_n, m.sv_n, m.mc_total, (int64_t)lds_normal(m), (int64_t)sizeof(DevModel), m.L, m.C, m.nl, m.nb, 0};
+    for (int i = 0; i < 16; i++) out16[i] = v[i];
+    return CPE_OK;
+}
 // diagnostic build only: per-phase shader-clock totals accumulated by block 0 of k_lm_step since the last call
 cpe_status cpe_debug_lm_stamps(unsigned long long* out16) {
     HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16));

@@ -90,6 +90,7 @@ struct DevModel {
     int32_t bodyang_legs_n[CPE_NX];
     int32_t bodyang_legs[CPE_NX][CPE_MAX_JOINTS];
     int32_t trunk_link[CPE_MAX_LINKS];              // links whose R / dR are needed (not leg links)
+    int32_t trunk_slot[CPE_MAX_LINKS];              // position of a link in trunk_link (R block = 36 doubles per slot), -1 for leg links
     // dynamic body-frame vectors: kind 0: sum_i Ry(alpha_{rev[i]}) vec[i] ; kind 1: dRy/dalpha(alpha_{rev[0]}) vec[0]
     int32_t sv_kind[CPE_MAX_SDYN], sv_cnt[CPE_MAX_SDYN], sv_rev[CPE_MAX_SDYN][3];
     double sv_vec[CPE_MAX_SDYN][3][3];
