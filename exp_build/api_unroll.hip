@@ -1,0 +1,628 @@
+// cpe_api.hip -- C ABI (include/cpe.h) over the HIP kernels.  gfx950 only, no CPU fallback:
+// every entry point fails with CPE_NO_DEVICE / CPE_HIP_ERROR when the GPU path is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../exp_build/k_unroll.hip"
+
+static thread_local std::string g_err;
+static cpe_status fail(cpe_status s, const std::string& m) { g_err = m; return s; }
+#define HIPCHK(x)                                                                                         \
+    do {                                                                                                  \
+        hipError_t e_ = (x);                                                                              \
+        if (e_ != hipSuccess) return fail(CPE_HIP_ERROR, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct cpe_handle {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    DevModel hm;                 // host copy
+    DevModel* dm = nullptr;      // device copy
+    cpe_options opts;
+    // solver workspace
+    size_t ws_frames = 0; int ws_B = 0;
+    double *qbuf = nullptr, *gbuf = nullptr, *Bbuf = nullptr, *costbuf = nullptr, *Lbuf = nullptr, *zbuf = nullptr,
+           *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr, *gambuf = nullptr;
+    SeqState* st = nullptr;
+    int* flag = nullptr;
+    // learned priors (config 3)
+    DevPriors* pri = nullptr;    // device copy, nullptr without priors
+    int gmm_k = 0, gmm_dim = 0, lr_window = 0;
+    double* Hlr = nullptr;       // [2][F][pb][nu*nu] off-diagonal Gauss-Newton blocks of the autoregressive prior
+    int pb = 3;                  // half-bandwidth of the normal equations in frames (4 with a window-4 motion prior)
+};
+
+static double host_rho0(double a, double b, double c) {
+    // rho(0) of acinoset_misc.py:2001-2015
+    auto sg = [](double t) { return 1.0 / (1.0 + std::exp(t)); };   // s(t, 0) = 1/(1+e^{t})
+    const double sa = sg(a), sb = sg(b), sc = sg(c);
+    const double cb = c - b, w = c / cb;
+    return (sa - sb) * (-0.5 * a * a) + (sb - sc) * (a * b - 0.5 * a * a + 0.5 * a * cb * (1.0 - w * w)) +
+           sc * (a * b - 0.5 * a * a + 0.5 * a * cb);
+}
+
+static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, DevModel& m) {
+    memset(&m, 0, sizeof(m));
+    if (s->n_links < 1 || s->n_links > CPE_MAX_LINKS || s->n_markers < 1 || s->n_markers > CPE_MAX_MARKERS ||
+        s->n_joints < 0 || s->n_joints > CPE_MAX_JOINTS || s->n_bounds < 0 || s->n_bounds > CPE_MAX_BOUNDS ||
+        C < 1 || C > CPE_MAX_CAMS)
+        return fail(CPE_BAD_ARG, "skeleton / camera counts out of range");
+    const int nl = s->n_links, nq = 3 + 3 * nl, L = s->n_markers;
+    m.nl = nl; m.L = L; m.C = C; m.nq = nq; m.nj = s->n_joints; m.nb = s->n_bounds;
+    m.h = o->h; m.ih2 = 1.0 / (o->h * o->h);
+    m.loss_a = o->loss_a; m.loss_b = o->loss_b; m.loss_c = o->loss_c;
+    m.bound_penalty = o->bound_penalty; m.curvature = o->curvature;
+    m.rho0 = host_rho0(o->loss_a, o->loss_b, o->loss_c);
+    if (!(o->h > 0)) return fail(CPE_BAD_ARG, "options.h must be > 0");
+    double mt = 0;
+    for (int i = 0; i < nl; i++) {
+        if (s->parent[i] >= i) return fail(CPE_BAD_ARG, "links must be ordered parents first");
+        m.parent[i] = s->parent[i];
+        for (int d = 0; d < 3; d++) { m.attach[i][d] = s->attach[i][d]; m.com[i][d] = s->com[i][d]; }
+        m.mass[i] = s->mass[i]; mt += s->mass[i];
+    }
+    m.inv_total_mass = mt > 0 ? 1.0 / mt : 0.0;
+    for (int c = 0; c < C; c++) m.cam[c] = cams[c];
+
+    // dependent / independent split
+    for (int p = 0; p < nq; p++) { m.u_of_q[p] = -1; m.dep_of_q[p] = -1; }
+    int ndep = 0;
+    std::vector<int> joint_of_child(nl, -1);
+    for (int j = 0; j < s->n_joints; j++) {
+        const int p = s->joint_parent[j], c = s->joint_child[j], k = s->joint_kind[j];
+        if (p < 0 || p >= nl || c <= p || c >= nl || joint_of_child[c] >= 0) return fail(CPE_BAD_ARG, "bad joint");
+        m.joint_parent[j] = p; m.joint_child[j] = c; m.joint_kind[j] = k;
+        joint_of_child[c] = j;
+        m.joint_dep0[j] = ndep;
+        m.dep_joint[ndep] = j;
+        m.dep_of_q[3 + 3 * c] = ndep++;
+        if (k == CPE_JOINT_REVOLUTE_Y) { m.dep_joint[ndep] = j; m.dep_of_q[3 + 3 * c + 2] = ndep++; }
+        else if (k != CPE_JOINT_HOOKE_YZ) return fail(CPE_BAD_ARG, "unknown joint kind");
+        if (ndep > CPE_MAX_DEP) return fail(CPE_BAD_ARG, "too many dependent angles");
+    }
+    m.ndep = ndep;
+    int nu = 0;
+    for (int p = 0; p < nq; p++)
+        if (m.dep_of_q[p] < 0) { if (nu >= CPE_NX) return fail(CPE_BAD_ARG, "more than 28 independent dofs"); m.indep[nu] = p; m.u_of_q[p] = nu++; }
+    m.nu = nu;
+    if (nu != CPE_NX) return fail(CPE_BAD_ARG, "the solver is built for exactly 28 independent dofs");
+    for (int p = 0; p < nq; p++)
+        if (m.dep_of_q[p] >= 0 && s->motion_w[p] != 0.0) return fail(CPE_BAD_ARG, "motion weight on a dependent angle");
+    for (int k = 0; k < nu; k++) {
+        const int p = m.indep[k];
+        m.motion_w_u[k] = s->motion_w[p];
+        m.rel_sign_u[k] = s->rel_ref[p] < 0 ? 1.0 : s->rel_sign[p];
+        m.rel_ref_u[k] = s->rel_ref[p] < 0 ? -1 : m.u_of_q[s->rel_ref[p]];
+        if (s->rel_ref[p] >= 0 && m.rel_ref_u[k] < 0) return fail(CPE_BAD_ARG, "relative angle references a dependent dof");
+    }
+    // joint bodies and S column layout
+    for (int j = 0; j < s->n_joints; j++) {
+        const int p = m.joint_parent[j], c = m.joint_child[j], r = m.joint_dep0[j];
+        if (m.joint_kind[j] == CPE_JOINT_REVOLUTE_Y) {
+            int body = p;
+            const int jp = joint_of_child[p];
+            if (jp >= 0) {
+                if (m.joint_kind[jp] != CPE_JOINT_REVOLUTE_Y) return fail(CPE_BAD_ARG, "revolute joint below a hooke joint is not supported");
+                body = m.joint_body[jp];
+            }
+            m.joint_body[j] = body;
+            for (int a = 0; a < 3; a++)
+                if (m.u_of_q[3 + 3 * body + a] < 0) return fail(CPE_BAD_ARG, "revolute chain must hang off a link with independent angles");
+            if (m.u_of_q[3 + 3 * c + 1] < 0) return fail(CPE_BAD_ARG, "theta of a revolute child must be independent");
+            for (int rr = r; rr < r + 2; rr++) {
+                m.scol_n[rr] = 4; m.dep_level[rr] = 0;
+                for (int a = 0; a < 3; a++) m.scol[rr][a] = m.u_of_q[3 + 3 * body + a];
+                m.scol[rr][3] = m.u_of_q[3 + 3 * c + 1];
+            }
+        } else {
+            m.joint_body[j] = p;
+            int n = 0;
+            auto add = [&](int col, int kind, int ang, int chain) -> bool {
+                for (int e = 0; e < n; e++)
+                    if (m.scol[r][e] == col) { if (chain >= 0) m.hk_chain[r][e] = (int16_t)chain; else { m.hk_kind[r][e] = (int8_t)kind; m.hk_ang[r][e] = (int8_t)ang; } return true; }
+                if (n >= CPE_MAX_SCOL) return false;
+                m.scol[r][n] = col; m.hk_kind[r][n] = (int8_t)kind; m.hk_ang[r][n] = (int8_t)ang; m.hk_chain[r][n] = (int16_t)chain; n++;
+                return true;
+            };
+            if (m.u_of_q[3 + 3 * c + 1] < 0 || m.u_of_q[3 + 3 * c + 2] < 0) return fail(CPE_BAD_ARG, "theta/psi of a hooke child must be independent");
+            bool ok = add(m.u_of_q[3 + 3 * c + 1], 0, 1, -1) && add(m.u_of_q[3 + 3 * c + 2], 0, 2, -1);
+            m.dep_level[r] = 0;
+            for (int a = 0; a < 3 && ok; a++) {
+                const int pq = 3 + 3 * p + a;
+                if (m.u_of_q[pq] >= 0) ok = add(m.u_of_q[pq], 1, a, -1);
+                else {
+                    if (a != 0) return fail(CPE_BAD_ARG, "hooke parent with dependent theta/psi is not supported");
+                    const int pr = m.dep_of_q[pq];
+                    if (m.dep_level[pr] != 0 || m.joint_kind[m.dep_joint[pr]] != CPE_JOINT_HOOKE_YZ)
+                        return fail(CPE_BAD_ARG, "hooke chains deeper than two are not supported");
+                    m.dep_level[r] = 1;
+                    for (int e = 0; e < m.scol_n[pr] && ok; e++) ok = add(m.scol[pr][e], 2, 0, pr * CPE_MAX_SCOL + e);
+                }
+            }
+            if (!ok) return fail(CPE_BAD_ARG, "too many columns in a hooke row");
+            m.scol_n[r] = n;
+        }
+    }
+    // revolute (leg) links: R_c = R_body Ry(alpha_c)
+    std::vector<int> rev_of_link(nl, -1);
+    m.nrev = 0;
+    for (int p = 0; p < nq; p++) m.euler_rev[p] = -1;
+    for (int k = 0; k < nu; k++) { m.rev_of_u[k] = -1; m.ucoord_src[k] = m.indep[k]; m.bodyang_j[k] = -1; m.bodyang_legs_n[k] = 0; }
+    for (int j = 0; j < s->n_joints; j++)
+        if (m.joint_kind[j] == CPE_JOINT_REVOLUTE_Y) {
+            const int r = m.nrev++, c = m.joint_child[j], Bk = m.joint_body[j];
+            rev_of_link[c] = r;
+            m.rev_child[r] = c; m.rev_body[r] = Bk; m.rev_u[r] = m.u_of_q[3 + 3 * c + 1];
+            m.rev_of_u[m.rev_u[r]] = r; m.euler_rev[3 + 3 * c + 1] = r;
+            for (int a = 0; a < 3; a++) {
+                const int kb = m.u_of_q[3 + 3 * Bk + a];
+                m.rev_body_u[r][a] = kb; m.bodyang_j[kb] = a;
+                m.bodyang_legs[kb][m.bodyang_legs_n[kb]++] = r;
+            }
+        }
+    m.ns = nq + m.nrev;
+    if (m.nrev > LM_MAX_REV) return fail(CPE_BAD_ARG, "more than 12 leg links");
+    for (int k = 0; k < nu; k++) if (m.bodyang_legs_n[k] > LM_MAX_LEGS) return fail(CPE_BAD_ARG, "more than 6 leg links on one body");
+    for (int r = 0; r < m.nrev; r++) m.ucoord_src[m.rev_u[r]] = nq + r;
+    m.n_trunk = 0;
+    for (int i = 0; i < nl; i++) { m.trunk_slot[i] = -1; if (rev_of_link[i] < 0) { m.trunk_slot[i] = m.n_trunk; m.trunk_link[m.n_trunk++] = i; } }
+    // marker chains and Jacobian slots
+    int S = 0, mct = 0, ss = 0, sv = 0;
+    for (int l = 0; l < L; l++) {
+        int chain[CPE_MAX_LINKS], n = 0, k = s->marker_link[l];
+        if (k < 0 || k >= nl) return fail(CPE_BAD_ARG, "bad marker link");
+        while (k >= 0) { chain[n++] = k; k = s->parent[k]; }
+        if (n > CPE_MAX_CHAIN) return fail(CPE_BAD_ARG, "marker chain too long");
+        m.chain_len[l] = n;
+        for (int i = 0; i < n; i++) {
+            const int link = chain[n - 1 - i];
+            m.chain_link[l][i] = link;
+            const double* v = i == n - 1 ? s->marker_off[l] : s->attach[chain[n - 2 - i]];
+            for (int d = 0; d < 3; d++) m.chain_vec[l][i][d] = v[d];
+        }
+        m.slot_off[l] = S;
+        if (S + 3 + 3 * n > CPE_MAX_SLOTS) return fail(CPE_BAD_ARG, "too many Jacobian slots");
+        for (int d = 0; d < 3; d++) { m.slot_marker[S] = l; m.slot_dof[S] = d; m.slot_cpos[S] = -1; m.slot_ang[S] = 0; S++; }
+        for (int i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++) { m.slot_marker[S] = l; m.slot_dof[S] = 3 + 3 * m.chain_link[l][i] + a; m.slot_cpos[S] = i; m.slot_ang[S] = a; S++; }
+        // ---- solver side: reduced columns of this marker.  Leg links are rotations of their body about its
+        // y axis (R_c = R_B Ry(alpha_c)); everything the legs contribute is a body matrix times a body-frame
+        // vector that depends on the alphas ("dynamic vectors").
+        int nc = 0;
+        auto col_index = [&](int col) -> int {
+            for (int e = 0; e < nc; e++) if (m.mcol[l][e] == col) return e;
+            if (nc >= CPE_MAX_MCOL) return -1;
+            m.mcol[l][nc] = col; m.term_n[l][nc] = 0; return nc++;
+        };
+        auto add_term = [&](int col, int slot, int sidx) -> bool {
+            const int e = col_index(col);
+            if (e < 0 || m.term_n[l][e] >= CPE_MAX_TERMS) return false;
+            m.term_slot[l][e][m.term_n[l][e]] = (int16_t)slot; m.term_s[l][e][m.term_n[l][e]] = (int16_t)sidx; m.term_n[l][e]++;
+            return true;
+        };
+        auto new_slot = [&](int moff, int vdyn, const double* v) -> int {
+            if (ss >= CPE_MAX_SLOTS) return -1;
+            m.ss_moff[ss] = moff; m.ss_vdyn[ss] = vdyn;
+            for (int d = 0; d < 3; d++) m.ss_vec[ss][d] = v ? v[d] : 0.0;
+            return ss++;
+        };
+        bool ok = true;
+        const double ex[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int d = 0; d < 3 && ok; d++) { const int sl = new_slot(-1, -1, ex[d]); ok = sl >= 0 && add_term(m.u_of_q[d], sl, -1); }
+        int n_trunk_chain = 0;
+        while (n_trunk_chain < n && rev_of_link[m.chain_link[l][n_trunk_chain]] < 0) n_trunk_chain++;
+        m.pc_len[l] = n_trunk_chain; m.pw_id[l] = -1; m.pw_body[l] = 0;
+        for (int i = 0; i < n_trunk_chain && ok; i++) {
+            const int link = m.chain_link[l][i];
+            m.pc_link[l][i] = link;
+            for (int d = 0; d < 3; d++) m.pc_vec[l][i][d] = m.chain_vec[l][i][d];
+            for (int a = 0; a < 3 && ok; a++) {
+                const int sl = new_slot(9 * (4 * m.trunk_slot[link] + 1 + a), -1, m.chain_vec[l][i]);
+                const int p = 3 + 3 * link + a;
+                if (sl < 0) { ok = false; break; }
+                if (m.u_of_q[p] >= 0) ok = add_term(m.u_of_q[p], sl, -1);
+                else { const int r = m.dep_of_q[p]; for (int e = 0; e < m.scol_n[r] && ok; e++) ok = add_term(m.scol[r][e], sl, r * CPE_MAX_SCOL + e); }
+            }
+        }
+        if (n_trunk_chain < n && ok) {
+            const int Bk = m.chain_link[l][n_trunk_chain - 1];
+            const int nleg = n - n_trunk_chain;
+            if (nleg > 3 || sv + 1 + nleg > CPE_MAX_SDYN) return fail(CPE_BAD_ARG, "leg chain too long");
+            const int wid = sv++;
+            m.sv_kind[wid] = 0; m.sv_cnt[wid] = nleg;
+            for (int i = 0; i < nleg; i++) {
+                const int link = m.chain_link[l][n_trunk_chain + i];
+                if (rev_of_link[link] < 0 || m.rev_body[rev_of_link[link]] != Bk) return fail(CPE_BAD_ARG, "leg links must follow their body in the marker chain");
+                m.sv_rev[wid][i] = rev_of_link[link];
+                for (int d = 0; d < 3; d++) m.sv_vec[wid][i][d] = m.chain_vec[l][n_trunk_chain + i][d];
+            }
+            m.pw_id[l] = wid; m.pw_body[l] = Bk;
+            for (int a = 0; a < 3 && ok; a++) {           // body angles act on the whole leg vector
+                const int sl = new_slot(9 * (4 * m.trunk_slot[Bk] + 1 + a), wid, nullptr);
+                ok = sl >= 0 && add_term(m.u_of_q[3 + 3 * Bk + a], sl, -1);
+            }
+            for (int i = 0; i < nleg && ok; i++) {        // alpha of each leg link
+                const int did = sv++;
+                m.sv_kind[did] = 1; m.sv_cnt[did] = 1; m.sv_rev[did][0] = m.sv_rev[wid][i];
+                for (int d = 0; d < 3; d++) m.sv_vec[did][0][d] = m.sv_vec[wid][i][d];
+                const int sl = new_slot(9 * (4 * m.trunk_slot[Bk]), did, nullptr);
+                ok = sl >= 0 && add_term(m.rev_u[m.sv_rev[wid][i]], sl, -1);
+            }
+        }
+        if (!ok) return fail(CPE_BAD_ARG, "marker depends on too many reduced dofs");
+        m.mcol_n[l] = nc; m.mcol_off[l] = mct;
+        for (int e = 0; e < nc; e++) { m.mc_marker[mct] = (int16_t)l; m.mc_j[mct] = (int16_t)e; mct++; }
+    }
+    m.ss_n = ss; m.sv_n = sv;
+    m.slot_off[L] = S; m.S = S; m.mcol_off[L] = mct; m.mc_total = mct;
+    if (S > 5 * WAVE) return fail(CPE_BAD_ARG, "more than 320 Jacobian slots");
+    for (int bnd = 0; bnd < s->n_bounds; bnd++) {
+        const int a = s->bound_a[bnd], bb = s->bound_b[bnd];
+        if (a < 0 || a >= nq || bb >= nq || m.u_of_q[a] < 0 || (bb >= 0 && m.u_of_q[bb] < 0))
+            return fail(CPE_BAD_ARG, "bounds must act on independent dofs");
+        m.bound_ua[bnd] = m.u_of_q[a]; m.bound_ub[bnd] = bb < 0 ? -1 : m.u_of_q[bb];
+        m.bound_lo[bnd] = s->bound_lo[bnd]; m.bound_up[bnd] = s->bound_up[bnd];
+    }
+    return CPE_OK;
+}
+
+static size_t lds_fk(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C); }
+static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0) {
+    // H | g overlay the solver-slot vectors dp and the S rows (dead once Dp is built): the larger of the two
+    size_t ov = 3 * m.ss_n + CPE_MAX_SCOL * m.ndep, hg = m.nu * m.nu + m.nu;
+    size_t n = m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.n_trunk + 3 * m.L + 3 * m.sv_n + GAM_STRIDE * m.nrev + (ov > hg ? ov : hg) +
+               9 * m.L + 3 * m.mc_total;
+    if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX + gmm_dim * gmm_dim + 2 * gmm_dim * m.nu;
+    return sizeof(double) * n;
+}
+
+extern "C" {
+
+const char* cpe_last_error(void) { return g_err.c_str(); }
+
+void cpe_default_options(cpe_options* o) {
+    o->h = 1.0 / 120.0; o->loss_a = 3.0; o->loss_b = 10.0; o->loss_c = 20.0; o->cost_scale = 1e-3;
+    o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-3; o->tol_step = 1e-8; o->tol_cost = 1e-12; o->max_iter = 200;
+    o->curvature = 0; o->max_outer = 8; o->_pad = 0;
+}
+
+cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts,
+                      const cpe_priors* priors, int32_t device, cpe_handle** out) {
+    if (!skel || !cams || !opts || !out) return fail(CPE_BAD_ARG, "null argument");
+    const bool use_pri = priors && (priors->gmm_k > 0 || priors->lr_window > 0);
+    if (use_pri) {
+        if (priors->gmm_k < 0 || priors->gmm_k > CPE_MAX_GMM || priors->gmm_dim < 0 || priors->gmm_dim > CPE_NX || (priors->gmm_k > 0 && priors->gmm_dim < 1))
+            return fail(CPE_BAD_ARG, "pose prior: component count / dimension out of range");
+        if (priors->lr_window < 0 || priors->lr_window > CPE_MAX_WINDOW) return fail(CPE_BAD_ARG, "motion prior: window out of range");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CPE_NO_DEVICE, "no HIP device: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(CPE_BAD_ARG, "device index out of range");
+    cpe_handle* h = new cpe_handle();
+    h->device = device; h->opts = *opts;
+    cpe_status s = build_model(skel, cams, n_cams, opts, h->hm);
+    if (s != CPE_OK) { delete h; return s; }
+    HIPCHK(hipSetDevice(device));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        // dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+        // dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+        const void* ks[] = {(const void*)&k_resjac<true, 4, RJ_OCC>, (const void*)&k_resjac<false, 4, RJ_OCC>};
+        for (const void* k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&h->dm, sizeof(DevModel)));
+    HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->flag, sizeof(int)));
+    if (use_pri) {
+        if (h->hm.nu != CPE_NX) return fail(CPE_BAD_ARG, "learned priors need the 28 relative angles of the reference's skeleton");
+        if (priors->gmm_k > 0 && priors->gmm_dim > h->hm.nu) return fail(CPE_BAD_ARG, "pose prior dimension exceeds the number of relative angles");
+        std::vector<DevPriors> hp(1);
+        DevPriors& P = hp[0];
+        memset(&P, 0, sizeof(P));
+        P.p = *priors;
+        const int W = priors->lr_window, nu = CPE_NX;
+        if (W > 0) {
+            // K_t[p][j]: lag blocks of slack = sum_t K_t x_{n-W+t} - b
+            auto K = [&](int t, int p2, int j) -> double { return t == W ? (p2 == j ? 1.0 : 0.0) : -priors->lr_coef[p2][t * nu + j]; };
+            for (int ta = 0; ta <= W; ta++)
+                for (int tb = 0; tb <= ta; tb++)
+                    for (int i = 0; i < nu; i++)
+                        for (int j = 0; j < nu; j++) {
+                            double a = 0.0;
+                            for (int p2 = 0; p2 < nu; p2++) a += K(ta, p2, i) * priors->lr_w[p2] * K(tb, p2, j);
+                            P.lr_PK[ta][tb][i * nu + j] = 2.0 * a;
+                        }
+            for (int k = 0; k <= W; k++)
+                for (int ta = k; ta <= W; ta++)
+                    for (int e = 0; e < nu * nu; e++) P.lr_HI[k][e] += P.lr_PK[ta][ta - k][e];
+        }
+        HIPCHK(hipMalloc(&h->pri, sizeof(DevPriors)));
+        HIPCHK(hipMemcpy(h->pri, &P, sizeof(DevPriors), hipMemcpyHostToDevice));
+        h->gmm_k = priors->gmm_k; h->gmm_dim = priors->gmm_dim; h->lr_window = W;
+        h->pb = W > 3 ? W : 3;
+    }
+    *out = h;
+    return CPE_OK;
+}
+
+static void free_ws(cpe_handle* h) {
+    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st, h->Hlr};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = h->Hlr = nullptr; h->st = nullptr;
+    h->ws_frames = 0; h->ws_B = 0;
+}
+
+void cpe_destroy(cpe_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    free_ws(h);
+    if (h->dm) (void)hipFree(h->dm);
+    if (h->flag) (void)hipFree(h->flag);
+    if (h->pri) (void)hipFree(h->pri);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+void* cpe_stream(cpe_handle* h) { return h ? (void*)h->stream : nullptr; }
+cpe_status cpe_synchronize(cpe_handle* h) {
+    if (!h) return fail(CPE_BAD_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CPE_OK;
+}
+
+int32_t cpe_jacobian_slots(const cpe_handle* h) { return h ? h->hm.S : 0; }
+cpe_status cpe_jacobian_layout(const cpe_handle* h, int32_t* slot_marker, int32_t* slot_dof) {
+    if (!h || !slot_marker || !slot_dof) return fail(CPE_BAD_ARG, "null argument");
+    for (int s = 0; s < h->hm.S; s++) { slot_marker[s] = h->hm.slot_marker[s]; slot_dof[s] = h->hm.slot_dof[s]; }
+    return CPE_OK;
+}
+int32_t cpe_num_independent(const cpe_handle* h) { return h ? h->hm.nu : 0; }
+cpe_status cpe_independent_dofs(const cpe_handle* h, int32_t* dofs) {
+    if (!h || !dofs) return fail(CPE_BAD_ARG, "null argument");
+    for (int k = 0; k < h->hm.nu; k++) dofs[k] = h->hm.indep[k];
+    return CPE_OK;
+}
+
+cpe_status cpe_eval_resjac(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
+                           double* r, double* J, double* eps, double* cost) {
+    if (!h || !q || !meas || !r || !J || !eps) return fail(CPE_BAD_ARG, "null argument");
+    if (cost && !weight) return fail(CPE_BAD_ARG, "cost requested without weights");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    HIPCHK(hipSetDevice(h->device));
+    const DevModel& m = h->hm;
+    if (m.L > WAVE || m.S > 5 * WAVE) return fail(CPE_BAD_ARG, "cpe_eval_resjac supports at most 64 markers and 320 Jacobian slots");
+    constexpr int NW = 4;                                   // waves (= frames in flight) per workgroup
+    const size_t lds = sizeof(double) * (((rj_shared_doubles(m.C, m.L, m.S) + 1) & ~1) + (size_t)NW * rj_wave_doubles(m.L, m.S, m.nq, m.nl));
+    int wg_per_cu = (int)((160 * 1024) / lds);
+    if (wg_per_cu < 1) return fail(CPE_BAD_ARG, "model too large for the LDS of one workgroup");
+    constexpr int OCC = RJ_OCC;                             // workgroups per CU the kernel is compiled for (waves/SIMD = OCC)
+    if (wg_per_cu > OCC) wg_per_cu = OCC;
+    long grid = (long)h->n_cu * wg_per_cu;
+    const long need = (long)((F + NW - 1) / NW);
+    if (grid > need) grid = need;
+    if (cost) hipLaunchKernelGGL((k_resjac<true, NW, OCC>), dim3((unsigned)grid), dim3(WAVE * NW), lds, h->stream, h->dm, N, (long)F, q, meas, weight, r, J, eps, cost);
+    else hipLaunchKernelGGL((k_resjac<false, NW, OCC>), dim3((unsigned)grid), dim3(WAVE * NW), lds, h->stream, h->dm, N, (long)F, q, meas, weight, r, J, eps, cost);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
+cpe_status cpe_project_joints(cpe_handle* h, int32_t B, int32_t N, double* q) {
+    if (!h || !q) return fail(CPE_BAD_ARG, "null argument");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemsetAsync(h->flag, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_project, dim3((unsigned)F), dim3(WAVE), sizeof(double) * (h->hm.nq + 6 * h->hm.nl), h->stream, h->dm, q, h->flag);
+    HIPCHK(hipGetLastError());
+    int fl = 0;
+    HIPCHK(hipMemcpyAsync(&fl, h->flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return fl ? CPE_NUMERICAL : CPE_OK;
+}
+
+cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q, double* positions, double* com) {
+    if (!h || !q || !positions) return fail(CPE_BAD_ARG, "null argument");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_fk, dim3((unsigned)F), dim3(WAVE), lds_fk(h->hm), h->stream, h->dm, q, positions, com);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
+static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
+    const size_t F = (size_t)B * N;
+    if (F <= h->ws_frames && B <= h->ws_B) return CPE_OK;
+    free_ws(h);
+    const int nq = h->hm.nq, nu = h->hm.nu;
+    HIPCHK(hipMalloc(&h->qbuf, sizeof(double) * 2 * F * h->hm.ns));
+    HIPCHK(hipMalloc(&h->gambuf, sizeof(double) * 2 * F * (size_t)(GAM_STRIDE * (h->hm.nrev > 0 ? h->hm.nrev : 1))));
+    HIPCHK(hipMalloc(&h->gbuf, sizeof(double) * 2 * F * nu));
+    HIPCHK(hipMalloc(&h->Bbuf, sizeof(double) * 2 * F * nu * nu));
+    HIPCHK(hipMalloc(&h->costbuf, sizeof(double) * 2 * F * COST_STRIDE));
+    HIPCHK(hipMalloc(&h->mu, sizeof(double) * (F * (size_t)(h->hm.nb > 0 ? h->hm.nb : 1) * 2)));
+    HIPCHK(hipMalloc(&h->Lbuf, sizeof(double) * F * (h->pb + 1) * nu * nu));
+    HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * F * nu));
+    HIPCHK(hipMalloc(&h->gtbuf, sizeof(double) * F * nu));
+    HIPCHK(hipMalloc(&h->cmax, sizeof(double) * F));
+    HIPCHK(hipMalloc(&h->st, sizeof(SeqState) * B));
+    if (h->lr_window > 0) HIPCHK(hipMalloc(&h->Hlr, sizeof(double) * 2 * F * h->pb * nu * nu));
+    h->ws_frames = F; h->ws_B = B;
+    return CPE_OK;
+}
+
+static cpe_status ensure_ws(cpe_handle* h, int B, int N);
+
+cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
+                           double* g, double* Bm, double* cost, double* gam, double* q_out) {
+    if (!h || !q || !meas || !weight || !g || !Bm || !cost) return fail(CPE_BAD_ARG, "null argument");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    cpe_status s = ensure_ws(h, B, N);
+    if (s != CPE_OK) return s;
+    const DevModel& m = h->hm;
+    hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q, h->qbuf);
+    HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
+    HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
+    HIPCHK(hipMemcpyAsync(g, h->gbuf, sizeof(double) * F * m.nu, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(Bm, h->Bbuf, sizeof(double) * F * m.nu * m.nu, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_gather_normal, dim3((unsigned)F), dim3(128), 0, h->stream, h->dm, F, h->qbuf, h->costbuf, h->gambuf, cost, gam, q_out);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
+cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas, const double* weight,
+                     double* q, double* dq, double* ddq, double* positions, double* meas_err, cpe_stats* stats) {
+    if (!h || !q_init || !meas || !weight || !q) return fail(CPE_BAD_ARG, "null argument");
+    if ((dq == nullptr) != (ddq == nullptr)) return fail(CPE_BAD_ARG, "dq and ddq must be given together");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    HIPCHK(hipSetDevice(h->device));
+    cpe_status s = ensure_ws(h, B, N);
+    if (s != CPE_OK) return s;
+    const DevModel& m = h->hm;
+    const size_t Fw = F;   // buffers are laid out for exactly this call's F (strides use F)
+    hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q_init, h->qbuf);   // Euler q -> (q, alpha)
+    HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
+    HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
+    LmParams prm;
+    prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
+    prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;
+    const size_t ldsn = lds_normal(m, h->gmm_k, h->gmm_dim);
+    const bool lr = h->lr_window > 0;
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
+    if (lr) hipLaunchKernelGGL(k_lr_band, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf, h->Hlr, h->costbuf);
+    auto lm_step = [&](int first) {
+        if (h->pb == 3) hipLaunchKernelGGL(k_lm_step<3>, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr);
+        else hipLaunchKernelGGL(k_lm_step<4>, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr);
+    };
+    lm_step(1);
+    HIPCHK(hipGetLastError());
+    std::vector<SeqState> hs(B);
+    const int rounds = h->opts.max_iter + 2 * (h->opts.max_outer > 0 ? h->opts.max_outer : 0);   // a multiplier update costs one extra round
+    for (int it = 0; it < rounds; it++) {
+        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
+        if (lr) hipLaunchKernelGGL(k_lr_band, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf, h->Hlr, h->costbuf);
+        lm_step(0);
+        if ((it & 7) == 7 || it == rounds - 1) {
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            bool running = false;
+            for (int b = 0; b < B; b++) running |= hs[b].status == 0;
+            if (!running) break;
+        }
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, Fw, h->qbuf, meas, q, dq, ddq, positions, meas_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    cpe_status worst = CPE_OK;
+    for (int b = 0; b < B; b++) {
+        const SeqState& S = hs[b];
+        const cpe_status sb = S.status == 1 ? CPE_OK : ((S.status == 0 || S.status == 3) ? CPE_MAX_ITER : CPE_NUMERICAL);
+        if (sb > worst) worst = sb;
+        if (stats) {
+            cpe_stats& o = stats[b];
+            o.status = sb; o.iterations = S.iters; o.lambda = S.lambda; o.max_constraint = 0.0;
+            o.max_bound_violation = S.maxviol; o.outer = S.outer; o._pad = 0;
+            o.cost_meas = S.terms[0]; o.cost_model = S.terms[1]; o.cost_pose = S.terms[3]; o.cost_motion = S.terms[4];
+            o.cost = h->opts.cost_scale * (S.terms[0] + S.terms[1] + S.terms[3] + S.terms[4]);
+        }
+    }
+    return worst;
+}
+
+#ifdef CPE_LM_STAMPS
+// diagnostic build only: table sizes and LDS bytes of the per-frame kernels for a model (needs no GPU)
+cpe_status cpe_debug_footprint(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts, int64_t* out16) {
+    std::vector<DevModel> mv(1);
+    cpe_status s = build_model(skel, cams, n_cams, opts, mv[0]);
+    if (s != CPE_OK) return s;
+    const DevModel& m = mv[0];
+    const int64_t v[16] = {m.nq, m.ns, m.nu, m.ndep, m.nrev, m.S, m.ss_n, m.sv_n, m.mc_total, (int64_t)lds_normal(m), (int64_t)sizeof(DevModel), m.L, m.C, m.nl, m.nb, 0};
+    for (int i = 0; i < 16; i++) out16[i] = v[i];
+    return CPE_OK;
+}
+// diagnostic build only: per-phase shader-clock totals accumulated by block 0 of k_lm_step since the last call
+cpe_status cpe_debug_lm_stamps(unsigned long long* out16) {
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lm_stamps), z, sizeof(z)));
+    return CPE_OK;
+}
+#endif
+
+// ---- host-pointer wrappers: stage through HBM (PCIe-inclusive; never the benchmarked path) -------------
+struct DevBuf {
+    double* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(double) * (n ? n : 1)); }
+};
+
+cpe_status cpe_eval_resjac_host(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
+                                double* r, double* J, double* eps, double* cost) {
+    if (!h || !q || !meas || !r || !J || !eps) return fail(CPE_BAD_ARG, "null argument");
+    const size_t F = (size_t)B * N; const DevModel& m = h->hm;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    DevBuf dq_, dm_, dw_, dr_, dJ_, de_, dc_;
+    const size_t nm = F * m.C * m.L;
+    HIPCHK(dq_.alloc(F * m.nq)); HIPCHK(dm_.alloc(nm * 2)); HIPCHK(dw_.alloc(nm)); HIPCHK(dr_.alloc(nm * 2));
+    HIPCHK(dJ_.alloc(F * m.C * m.S * 2)); HIPCHK(de_.alloc(F * m.nq)); HIPCHK(dc_.alloc(F));
+    HIPCHK(hipMemcpyAsync(dq_.p, q, sizeof(double) * F * m.nq, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dm_.p, meas, sizeof(double) * nm * 2, hipMemcpyHostToDevice, h->stream));
+    if (weight) HIPCHK(hipMemcpyAsync(dw_.p, weight, sizeof(double) * nm, hipMemcpyHostToDevice, h->stream));
+    cpe_status s = cpe_eval_resjac(h, B, N, dq_.p, dm_.p, weight ? dw_.p : nullptr, dr_.p, dJ_.p, de_.p, (cost && weight) ? dc_.p : nullptr);
+    if (s != CPE_OK) return s;
+    HIPCHK(hipMemcpyAsync(r, dr_.p, sizeof(double) * nm * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(J, dJ_.p, sizeof(double) * F * m.C * m.S * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(eps, de_.p, sizeof(double) * F * m.nq, hipMemcpyDeviceToHost, h->stream));
+    if (cost && weight) HIPCHK(hipMemcpyAsync(cost, dc_.p, sizeof(double) * F, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CPE_OK;
+}
+
+cpe_status cpe_solve_host(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas, const double* weight,
+                          double* q, double* dq, double* ddq, double* positions, double* meas_err, cpe_stats* stats) {
+    if (!h || !q_init || !meas || !weight || !q) return fail(CPE_BAD_ARG, "null argument");
+    const size_t F = (size_t)B * N; const DevModel& m = h->hm;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t nm = F * m.C * m.L;
+    DevBuf di, dm_, dw_, oq, odq, oddq, op, ome;
+    HIPCHK(di.alloc(F * m.nq)); HIPCHK(dm_.alloc(nm * 2)); HIPCHK(dw_.alloc(nm)); HIPCHK(oq.alloc(F * m.nq));
+    HIPCHK(odq.alloc(F * m.nq)); HIPCHK(oddq.alloc(F * m.nq)); HIPCHK(op.alloc(F * m.L * 3)); HIPCHK(ome.alloc(nm * 2));
+    HIPCHK(hipMemcpyAsync(di.p, q_init, sizeof(double) * F * m.nq, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dm_.p, meas, sizeof(double) * nm * 2, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dw_.p, weight, sizeof(double) * nm, hipMemcpyHostToDevice, h->stream));
+    cpe_status s = cpe_solve(h, B, N, di.p, dm_.p, dw_.p, oq.p, odq.p, oddq.p, op.p, ome.p, stats);
+    if (s < 0) return s;
+    HIPCHK(hipMemcpyAsync(q, oq.p, sizeof(double) * F * m.nq, hipMemcpyDeviceToHost, h->stream));
+    if (dq) HIPCHK(hipMemcpyAsync(dq, odq.p, sizeof(double) * F * m.nq, hipMemcpyDeviceToHost, h->stream));
+    if (ddq) HIPCHK(hipMemcpyAsync(ddq, oddq.p, sizeof(double) * F * m.nq, hipMemcpyDeviceToHost, h->stream));
+    if (positions) HIPCHK(hipMemcpyAsync(positions, op.p, sizeof(double) * F * m.L * 3, hipMemcpyDeviceToHost, h->stream));
+    if (meas_err) HIPCHK(hipMemcpyAsync(meas_err, ome.p, sizeof(double) * nm * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return s;
+}
+
+}  // extern "C"

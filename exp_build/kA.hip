@@ -1,0 +1,381 @@
+// cpe_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): one 64-lane wavefront per frame.
+//
+//   k_resjac        metric 1: reprojection residual + sparse Jacobian + acceleration slack per frame
+//   k_fk            marker positions + centre of mass
+//   k_project       closed-form solve of the joint equalities for the dependent angles
+//   k_frame_normal  solver: per-frame cost, reduced gradient g[28] and PSD block B[28x28]
+//   k_lm_step       solver: one Levenberg-Marquardt step per sequence (block-banded Cholesky over time)
+//   k_finalize      solver outputs (q, dq, ddq, positions, meas_err, cost terms)
+//
+// Data layout in HBM (all fp64, frame-major, so a wave's loads/stores of one frame are contiguous):
+//   q[B][N][nq]  meas[B][N][C][L][2]  weight[B][N][C][L]  r[B][N][C][L][2]  J[B][N][C][S][2]  eps[B][N][nq]
+// No MFMA: nothing here is a dense contraction larger than 28x28.
+#include <hip/hip_runtime.h>
+
+#include "cpe_device.h"
+
+// --------------------------------------------------------------------------------------------------
+// shared wave-level building blocks.  LDS arrays are private to the wave (one wave per workgroup).
+
+// sincos of all link angles of the frame held in sq -> ssc[6*link + 2*ang + {0,1}]
+__device__ __forceinline__ void wave_sincos(const DevModel* __restrict__ M, const double* sq, double* ssc, int lane) {
+    if (lane < 3 * M->nl) {
+        double s, c;
+        sincos(sq[3 + lane], &s, &c);
+        ssc[2 * lane] = s; ssc[2 * lane + 1] = c;
+    }
+}
+
+// R and dR/d(phi,theta,psi) of every link -> sR[9*(4*link + kind)]
+__device__ __forceinline__ void wave_rotations(const DevModel* __restrict__ M, const double* ssc, double* sR, int lane) {
+    for (int t = lane; t < 4 * M->nl; t += WAVE) rot_kind(ssc + 6 * (t >> 2), t & 3, sR + 9 * t);
+}
+
+// marker positions p_l = x_base + sum_k R_k v_lk  (acinoset_misc.py:1581-1659)
+__device__ __forceinline__ void wave_markers(const DevModel* __restrict__ M, const double* sq, const double* sR,
+                                             double* spos, int lane) {
+    if (lane < M->L) {
+        double p0 = sq[0], p1 = sq[1], p2 = sq[2];
+        const int n = M->chain_len[lane];
+        for (int k = 0; k < n; k++) {
+            const double* R = sR + 36 * M->chain_link[lane][k];
+            const double v0 = M->chain_vec[lane][k][0], v1 = M->chain_vec[lane][k][1], v2 = M->chain_vec[lane][k][2];
+            p0 += R[0] * v0 + R[1] * v1 + R[2] * v2;
+            p1 += R[3] * v0 + R[4] * v1 + R[5] * v2;
+            p2 += R[6] * v0 + R[7] * v1 + R[8] * v2;
+        }
+        spos[3 * lane] = p0; spos[3 * lane + 1] = p1; spos[3 * lane + 2] = p2;
+    }
+}
+
+// d p_marker / d q_dof for Jacobian slot s
+__device__ __forceinline__ void slot_dp(const DevModel* __restrict__ M, const double* sR, int s, double& d0, double& d1, double& d2) {
+    const int cpos = M->slot_cpos[s];
+    if (cpos < 0) {
+        const int ax = M->slot_dof[s];
+        d0 = ax == 0 ? 1.0 : 0.0; d1 = ax == 1 ? 1.0 : 0.0; d2 = ax == 2 ? 1.0 : 0.0;
+    } else {
+        const int l = M->slot_marker[s];
+        const double* D = sR + 9 * (4 * M->chain_link[l][cpos] + 1 + M->slot_ang[s]);
+        const double v0 = M->chain_vec[l][cpos][0], v1 = M->chain_vec[l][cpos][1], v2 = M->chain_vec[l][cpos][2];
+        d0 = D[0] * v0 + D[1] * v1 + D[2] * v2;
+        d1 = D[3] * v0 + D[4] * v1 + D[5] * v2;
+        d2 = D[6] * v0 + D[7] * v1 + D[8] * v2;
+    }
+}
+
+// closed-form solution of the joint equalities for the dependent angles (branch
+// child.y = +parent.y reached from the reference's initial guess, acinoset_opt.py:574-583).
+// Updates sq and ssc in place; returns non-zero in every lane if some revolute child sits in the gimbal
+// band |cos(theta)| < |a_z| where the equalities have no solution.
+__device__ __forceinline__ int wave_project_joints(const DevModel* __restrict__ M, double* sq, double* ssc, int lane, bool hooke_only = false) {
+    int clamped = 0;
+    for (int level = 0; level < 2; level++) {
+        if (lane < M->nj && !(hooke_only && M->joint_kind[lane] == CPE_JOINT_REVOLUTE_Y)) {
+            const int kind = M->joint_kind[lane], p = M->joint_parent[lane], c = M->joint_child[lane];
+            const bool lvl1 = kind == CPE_JOINT_HOOKE_YZ && M->dep_of_q[3 + 3 * p] >= 0;   // parent phi is itself dependent
+            if ((level == 1) == lvl1) {
+                double a[3];
+                const double st = ssc[6 * c + 2], ct = ssc[6 * c + 3];
+                if (kind == CPE_JOINT_REVOLUTE_Y) {
+                    rot_ycol(ssc + 6 * M->joint_body[lane], a);
+                    double sphi = a[2] / ct;
+                    if (sphi > 1.0) { sphi = 1.0; clamped = 1; }
+                    if (sphi < -1.0) { sphi = -1.0; clamped = 1; }
+                    const double cphi = sqrt(fmax(0.0, 1.0 - sphi * sphi));
+                    double psi = atan2(a[1], a[0]) - atan2(cphi, sphi * st);
+                    const double ref = sq[3 + 3 * p + 2];
+                    psi += 6.283185307179586476925286766559 * rint((ref - psi) / 6.283185307179586476925286766559);
+                    sq[3 + 3 * c] = asin(sphi); sq[3 + 3 * c + 2] = psi;
+                    ssc[6 * c] = sphi; ssc[6 * c + 1] = cphi;
+                    double s, co; cpe_sincos(psi, &s, &co);
+                    ssc[6 * c + 4] = s; ssc[6 * c + 5] = co;
+                } else {
+                    rot_ycol(ssc + 6 * p, a);
+                    const double sp = ssc[6 * c + 4], cp = ssc[6 * c + 5];
+                    const double num = a[0] * st * cp + a[1] * st * sp + a[2] * ct;
+                    const double den = a[1] * cp - a[0] * sp;
+                    const double hyp = sqrt(num * num + den * den);
+                    sq[3 + 3 * c] = atan2(num, den);
+                    ssc[6 * c] = num / hyp; ssc[6 * c + 1] = den / hyp;
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+    return __any(clamped);
+}
+
+// --------------------------------------------------------------------------------------------------
+// metric 1 kernel: residual + sparse Jacobian + acceleration slack.
+//
+// Persistent workgroups of NW waves; every wave owns one frame at a time and walks the frame list with a
+// grid stride.  Read-only model tables (cameras, Jacobian-slot table, marker-chain table) are staged ONCE
+// per workgroup in LDS, so the per-frame code has no dependent global loads; the next frame's q / meas /
+// neighbour-q are prefetched into registers while the current frame computes and stores.
+// LDS (doubles): shared  cam[23C] | ident[10] | slot[4S] | chain[4*L*MAXCHAIN] | clen[(L+1)/2]
+//                per wave A[max(3S, nq+6nl+36nl)] | G[6*cpp*L] | pos[3L(+1)]
+//   A = {q, sin/cos, R & dR} while the chain runs, then the slot vectors dp = dR.v as [3][S] (they used to live in 30
+//   registers per lane across the projection: 229 VGPRs, 2 waves/SIMD); G = the 2x3 projection Jacobians of the
+//   cpp = 64/L cameras of the current pass.
+// Tables are structure-of-arrays so that consecutive lanes touch consecutive LDS words (no bank conflicts):
+//   slot:  v0[S] v1[S] v2[S] (double) | doff[S] marker[S] (int32; doff = offset of the 3x3 dR in the wave's R block, <0: identity)
+//   chain: v0[K][L] v1[K][L] v2[K][L] (double) | roff[K][L] (int32), K = CPE_MAX_CHAIN, marker index fastest
+__host__ __device__ inline int rj_shared_doubles(int C, int L, int S) {
+    return 23 * C + 10 + 3 * S + (2 * S + 1) / 2 + 3 * L * CPE_MAX_CHAIN + (L * CPE_MAX_CHAIN + 1) / 2 + (L + 1) / 2;
+}
+__host__ __device__ inline int rj_region_a(int S, int nq, int nl) {
+    const int a = 3 * S, b = nq + 6 * nl + 36 * nl;
+    return ((a > b ? a : b) + 1) & ~1;
+}
+__host__ __device__ inline int rj_wave_doubles(int L, int S, int nq, int nl) {
+    return (rj_region_a(S, nq, nl) + 6 * (WAVE / L) * L + 3 * L + 3) & ~1;
+}
+
+#ifndef RJ_OCC
+#define RJ_OCC 3      // workgroups of 4 waves per CU = waves per SIMD
+#endif
+template <bool WANT_COST, int NW, int OCC>
+__global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevModel* __restrict__ M, int N, long F,
+                                                      const double* __restrict__ q, const double* __restrict__ meas,
+                                                      const double* __restrict__ weight, double* __restrict__ r,
+                                                      double* __restrict__ J, double* __restrict__ eps,
+                                                      double* __restrict__ cost) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = M->nq, nl = M->nl, L = M->L, C = M->C, S = M->S, CL = C * L;
+    const int cpp = WAVE / L;                                               // cameras per projection pass
+    double* scam = smem;
+    double* sident = scam + 23 * C;
+    double* slv = sident + 10;                                              // slot vectors [3][S]
+    int* sli = reinterpret_cast<int*>(slv + 3 * S);                         // doff[S], marker[S]
+    double* chv = slv + 3 * S + (2 * S + 1) / 2;                            // chain vectors [3][K][L]
+    int* chr = reinterpret_cast<int*>(chv + 3 * L * CPE_MAX_CHAIN);         // roff[K][L]
+    int* sclen = reinterpret_cast<int*>(chv + 3 * L * CPE_MAX_CHAIN + (L * CPE_MAX_CHAIN + 1) / 2);
+    double* wbase = smem + ((rj_shared_doubles(C, L, S) + 1) & ~1);
+    double* wv = wbase + wave * rj_wave_doubles(L, S, nq, nl);
+    double* sq = wv;
+    double* ssc = sq + nq;
+    double* sR = ssc + 6 * nl;
+    double* sdp = wv;                      // overlays q / sincos / R once they are dead
+    double* sG = wv + rj_region_a(S, nq, nl);
+    double* spos = sG + 6 * cpp * L;
+
+    // ---- stage the model tables (once per workgroup)
+    for (int t = tid; t < 23 * C; t += WAVE * NW) scam[t] = reinterpret_cast<const double*>(M->cam)[t];
+    if (tid < 9) sident[tid] = (tid == 0 || tid == 4 || tid == 8) ? 1.0 : 0.0;
+    for (int s = tid; s < S; s += WAVE * NW) {
+        const int l = M->slot_marker[s], cpos = M->slot_cpos[s];
+        sli[S + s] = l;
+        if (cpos < 0) {
+            const int ax = M->slot_dof[s];
+            slv[s] = ax == 0 ? 1.0 : 0.0; slv[S + s] = ax == 1 ? 1.0 : 0.0; slv[2 * S + s] = ax == 2 ? 1.0 : 0.0; sli[s] = -1;
+        } else {
+            slv[s] = M->chain_vec[l][cpos][0]; slv[S + s] = M->chain_vec[l][cpos][1]; slv[2 * S + s] = M->chain_vec[l][cpos][2];
+            sli[s] = 9 * (4 * M->chain_link[l][cpos] + 1 + M->slot_ang[s]);
+        }
+    }
+    for (int t = tid; t < L * CPE_MAX_CHAIN; t += WAVE * NW) {
+        const int k = t / L, l = t - k * L;
+        const bool on = k < M->chain_len[l];
+        chv[t] = on ? M->chain_vec[l][k][0] : 0.0;
+        chv[L * CPE_MAX_CHAIN + t] = on ? M->chain_vec[l][k][1] : 0.0;
+        chv[2 * L * CPE_MAX_CHAIN + t] = on ? M->chain_vec[l][k][2] : 0.0;
+        chr[t] = on ? 36 * M->chain_link[l][k] : 0;
+    }
+    for (int t = tid; t < L; t += WAVE * NW) sclen[t] = M->chain_len[t];
+    const double ih2 = M->ih2, la = M->loss_a, lb = M->loss_b, lc = M->loss_c;
+    __syncthreads();
+
+    const cpe_camera* cams = reinterpret_cast<const cpe_camera*>(scam);
+    const long wstride = (long)gridDim.x * NW;
+    long f = (long)blockIdx.x * NW + wave;
+    const double2* meas2 = reinterpret_cast<const double2*>(meas);
+
+    // q of the NEXT frame is prefetched one frame ahead (it is needed at once); the measurements of a camera group are
+    // fetched one group ahead; the three predecessor q's during the last group.
+    double qreg = 0.0;
+    if (f < F && lane < nq) qreg = q[f * nq + lane];
+
+    while (f < F) {
+        if (lane < nq) sq[lane] = qreg;
+        const long fn = f + wstride;
+        const long pair0 = f * CL;
+        double qn = 0.0;
+        if (lane < nq && fn < F) qn = q[fn * nq + lane];
+        double2 mzc = make_double2(0.0, 0.0);
+        if (lane < (cpp < C ? cpp : C) * L) mzc = meas2[pair0 + lane];
+        const bool has_prev = (int)(f % N) >= 3;
+        wave_lds_sync();
+        wave_sincos(M, sq, ssc, lane);
+        wave_lds_sync();
+        for (int t = lane; t < 4 * nl; t += WAVE) rot_kind(ssc + 6 * (t >> 2), t & 3, sR + 9 * t);
+        wave_lds_sync();
+        // marker positions from the LDS chain table
+        if (lane < L) {
+            double p0 = sq[0], p1 = sq[1], p2 = sq[2];
+            const int n = sclen[lane];
+            const int KL = L * CPE_MAX_CHAIN;
+#pragma unroll 1
+            for (int k = 0; k < n; k++) {   // not unrolled: the unroller's 16 hoisted address registers get spilled
+                const int t = k * L + lane;
+                const double v0 = chv[t], v1 = chv[KL + t], v2 = chv[2 * KL + t];
+                const double* R = sR + chr[t];
+                p0 += R[0] * v0 + R[1] * v1 + R[2] * v2;
+                p1 += R[3] * v0 + R[4] * v1 + R[5] * v2;
+                p2 += R[6] * v0 + R[7] * v1 + R[8] * v2;
+            }
+            spos[3 * lane] = p0; spos[3 * lane + 1] = p1; spos[3 * lane + 2] = p2;
+        }
+        // d p / d q of my Jacobian slots (slot s = lane + 64 i): computed from R, then parked in LDS over R
+        {
+            double dp0[5], dp1[5], dp2[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int s = lane + WAVE * i;
+                dp0[i] = dp1[i] = dp2[i] = 0.0;
+                if (s < S) {
+                    const int doff = sli[s];
+                    const double v0 = slv[s], v1 = slv[S + s], v2 = slv[2 * S + s];
+                    const double* D = doff < 0 ? sident : sR + doff;
+                    dp0[i] = D[0] * v0 + D[1] * v1 + D[2] * v2;
+                    dp1[i] = D[3] * v0 + D[4] * v1 + D[5] * v2;
+                    dp2[i] = D[6] * v0 + D[7] * v1 + D[8] * v2;
+                }
+            }
+            wave_lds_sync();        // R, sincos, q are dead from here
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int s = lane + WAVE * i;
+                if (s < S) { sdp[s] = dp0[i]; sdp[S + s] = dp1[i]; sdp[2 * S + s] = dp2[i]; }
+            }
+        }
+        wave_lds_sync();
+
+        // camera groups: project the group's (camera, marker) pairs (residual out, d(u,v)/dp to LDS), then store the J
+        // rows of those cameras: J[c][s][0..1] = G_{c,marker(s)} . dp_s, 16-byte stores, consecutive lanes -> consecutive slots
+        double2* Jf = reinterpret_cast<double2*>(J) + f * (long)(C * S);
+        double fc = 0.0;
+        double qp1 = 0.0, qp2 = 0.0, qp3 = 0.0;
+        for (int c0 = 0; c0 < C; c0 += cpp) {
+            const int nc = C - c0 < cpp ? C - c0 : cpp;
+            const int c1 = c0 + cpp;
+            double2 mzn = make_double2(0.0, 0.0);
+            if (c1 < C) { if (lane < (C - c1 < cpp ? C - c1 : cpp) * L) mzn = meas2[pair0 + c1 * L + lane]; }
+            else if (has_prev && lane < nq) { const double* qf = q + f * nq + lane; qp1 = qf[-nq]; qp2 = qf[-2 * nq]; qp3 = qf[-3 * nq]; }
+            if (lane < nc * L) {
+                const int cl = lane / L, l = lane - cl * L, c = c0 + cl;
+                double u, v, G[6];
+                project_point(cams[c], spos[3 * l], spos[3 * l + 1], spos[3 * l + 2], u, v, G);
+                const double e0 = u - mzc.x, e1 = v - mzc.y;
+                reinterpret_cast<double2*>(r)[pair0 + c0 * L + lane] = make_double2(e0, e1);
+                double2* Gd = reinterpret_cast<double2*>(sG + 6 * lane);
+                Gd[0] = make_double2(G[0], G[1]); Gd[1] = make_double2(G[2], G[3]); Gd[2] = make_double2(G[4], G[5]);
+                if (WANT_COST) {
+                    const double w = cams[c].mult * weight[pair0 + c0 * L + lane];
+                    fc += robust_loss(w * e0, la, lb, lc, 0, false).rho + robust_loss(w * e1, la, lb, lc, 0, false).rho;
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int s = lane + WAVE * i;
+                if (s < S) {
+                    const int mk = sli[S + s];
+                    const double d0 = sdp[s], d1 = sdp[S + s], d2 = sdp[2 * S + s];
+#pragma unroll 1
+                    for (int cl = 0; cl < nc; cl++) {
+                        const double2* G = reinterpret_cast<const double2*>(sG + 6 * (cl * L + mk));
+                        const double2 g0 = G[0], g1 = G[1], g2 = G[2];
+                        Jf[(c0 + cl) * S + s] = make_double2(g0.x * d0 + g0.y * d1 + g1.x * d2, g1.y * d0 + g2.x * d1 + g2.y * d2);
+                    }
+                }
+            }
+            wave_lds_sync();        // G is rewritten by the next group
+            mzc = mzn;
+        }
+        if (WANT_COST) {
+            fc = wave_sum(fc);
+            if (lane == 0) cost[f] = fc;
+        }
+        // acceleration slack of the constant-acceleration model (free dq0/ddq0 => 0 for n < 3)
+        if (lane < nq) {
+            double e = 0.0;
+            if (has_prev) e = (qreg - 3.0 * qp1 + 3.0 * qp2 - qp3) * ih2;
+            eps[f * nq + lane] = e;
+        }
+        qreg = qn;
+        f = fn;
+        wave_lds_sync();        // the dp region is rewritten as q / sincos / R by the next frame
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// forward kinematics: positions[F][L][3], com[F][3] (acinoset_misc.py:1581-1659, :722-742)
+// dynamic LDS: q[nq] | sc[6 nl] | R[36 nl] | pos[3 L]
+__global__ __launch_bounds__(WAVE) void k_fk(const DevModel* __restrict__ M, const double* __restrict__ q,
+                                             double* __restrict__ positions, double* __restrict__ com) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int nq = M->nq, nl = M->nl, L = M->L;
+    double* sq = smem;
+    double* ssc = sq + nq;
+    double* sR = ssc + 6 * nl;
+    double* spos = sR + 36 * nl;
+    const size_t f = blockIdx.x;
+    if (lane < nq) sq[lane] = q[f * nq + lane];
+    wave_lds_sync();
+    wave_sincos(M, sq, ssc, lane);
+    wave_lds_sync();
+    for (int t = lane; t < nl; t += WAVE) rot_kind(ssc + 6 * t, 0, sR + 36 * t);
+    wave_lds_sync();
+    wave_markers(M, sq, sR, spos, lane);
+    wave_lds_sync();
+    for (int t = lane; t < 3 * L; t += WAVE) positions[f * (size_t)(3 * L) + t] = spos[t];
+    if (com) {
+        // link origins by walking up the chain (depth <= CPE_MAX_CHAIN), one lane per link
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (lane < nl) {
+            const double* R = sR + 36 * lane;
+            double p0 = R[0] * M->com[lane][0] + R[1] * M->com[lane][1] + R[2] * M->com[lane][2];
+            double p1 = R[3] * M->com[lane][0] + R[4] * M->com[lane][1] + R[5] * M->com[lane][2];
+            double p2 = R[6] * M->com[lane][0] + R[7] * M->com[lane][1] + R[8] * M->com[lane][2];
+            int k = lane;
+            while (M->parent[k] >= 0) {
+                const int p = M->parent[k];
+                const double* Rp = sR + 36 * p;
+                p0 += Rp[0] * M->attach[k][0] + Rp[1] * M->attach[k][1] + Rp[2] * M->attach[k][2];
+                p1 += Rp[3] * M->attach[k][0] + Rp[4] * M->attach[k][1] + Rp[5] * M->attach[k][2];
+                p2 += Rp[6] * M->attach[k][0] + Rp[7] * M->attach[k][1] + Rp[8] * M->attach[k][2];
+                k = p;
+            }
+            const double m = M->mass[lane];
+            c0 = m * (p0 + sq[0]); c1 = m * (p1 + sq[1]); c2 = m * (p2 + sq[2]);
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+        if (lane == 0) {
+            com[3 * f] = c0 * M->inv_total_mass; com[3 * f + 1] = c1 * M->inv_total_mass; com[3 * f + 2] = c2 * M->inv_total_mass;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// dependent-angle projection in place.  dynamic LDS: q[nq] | sc[6 nl]
+__global__ __launch_bounds__(WAVE) void k_project(const DevModel* __restrict__ M, double* __restrict__ q,
+                                                  int* __restrict__ clamped_flag) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int nq = M->nq;
+    double* sq = smem;
+    double* ssc = sq + nq;
+    const size_t f = blockIdx.x;
+    if (lane < nq) sq[lane] = q[f * nq + lane];
+    wave_lds_sync();
+    wave_sincos(M, sq, ssc, lane);
+    wave_lds_sync();
+    const int cl = wave_project_joints(M, sq, ssc, lane);
+    if (lane < nq) q[f * nq + lane] = sq[lane];
+    if (cl && lane == 0 && clamped_flag) atomicOr(clamped_flag, 1);
+}
+
+#include "cpe_solver.hip.inc"
