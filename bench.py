@@ -182,7 +182,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                          "traffic": pmc_traffic(B, N, C, L), "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(sk, cams, opts, d)
         print(json.dumps(out))
     h.close()

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "cpe_kernels.hip"
 
@@ -263,6 +264,38 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
     m.ss_n = ss; m.sv_n = sv;
     m.slot_off[L] = S; m.S = S; m.mcol_off[L] = mct; m.mc_total = mct;
     if (S > 5 * WAVE) return fail(CPE_BAD_ARG, "more than 320 Jacobian slots");
+    {   // gather lists for H and g (see cpe_model.h)
+        const int nu_ = m.nu;
+        std::vector<std::vector<uint32_t>> by_entry(nu_ * nu_);
+        for (int l = 0; l < L; l++)
+            for (int i = 0; i < m.mcol_n[l]; i++)
+                for (int j = 0; j <= i; j++) {
+                    int a = m.mcol[l][i], b = m.mcol[l][j];
+                    if (a < b) std::swap(a, b);
+                    by_entry[a * nu_ + b].push_back((uint32_t)(m.mcol_off[l] + i) | ((uint32_t)(m.mcol_off[l] + j) << 8) | ((uint32_t)l << 16));
+                }
+        std::vector<int> order;
+        for (int e = 0; e < nu_ * nu_; e++) if (!by_entry[e].empty()) order.push_back(e);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return by_entry[x].size() != by_entry[y].size() ? by_entry[x].size() > by_entry[y].size() : x < y; });
+        int load[64] = {0};
+        for (int e : order) {
+            int best = 0;
+            for (int ln = 1; ln < 64; ln++) if (load[ln] < load[best]) best = ln;
+            if (load[best] + (int)by_entry[e].size() > CPE_MAX_HG) return fail(CPE_BAD_ARG, "normal-matrix gather list too long");
+            const uint32_t ab = (uint32_t)(((e / nu_) << 5) | (e % nu_));
+            for (size_t k = 0; k < by_entry[e].size(); k++) m.hg_code[load[best] + k][best] = by_entry[e][k] | (k == 0 ? 1u << 21 : 0u) | (ab << 22);
+            load[best] += (int)by_entry[e].size();
+        }
+        m.hg_max = 0;
+        for (int ln = 0; ln < 64; ln++) { m.hg_cnt[ln] = load[ln]; if (load[ln] > m.hg_max) m.hg_max = load[ln]; }
+        for (int k = 0; k < nu_; k++) m.gg_cnt[k] = 0;
+        for (int l = 0; l < L; l++)
+            for (int i = 0; i < m.mcol_n[l]; i++) {
+                const int a = m.mcol[l][i];
+                if (m.gg_cnt[a] >= CPE_MAX_GG) return fail(CPE_BAD_ARG, "gradient gather list too long");
+                m.gg_code[m.gg_cnt[a]++][a] = (uint16_t)((m.mcol_off[l] + i) | (l << 8));
+            }
+    }
     for (int bnd = 0; bnd < s->n_bounds; bnd++) {
         const int a = s->bound_a[bnd], bb = s->bound_b[bnd];
         if (a < 0 || a >= nq || bb >= nq || m.u_of_q[a] < 0 || (bb >= 0 && m.u_of_q[bb] < 0))
@@ -566,6 +599,12 @@ cpe_status cpe_debug_footprint(const cpe_skeleton* skel, const cpe_camera* cams,
     const DevModel& m = mv[0];
     const int64_t v[16] = {m.nq, m.ns, m.nu, m.ndep, m.nrev, m.S, m.ss_n, m.sv_n, m.mc_total, (int64_t)lds_normal(m), (int64_t)sizeof(DevModel), m.L, m.C, m.nl, m.nb, 0};
     for (int i = 0; i < 16; i++) out16[i] = v[i];
+    return CPE_OK;
+}
+cpe_status cpe_debug_fn_stamps(unsigned long long* out16) {
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fn_stamps), sizeof(unsigned long long) * 16));
+    unsigned long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fn_stamps), z, sizeof(z)));
     return CPE_OK;
 }
 // diagnostic build only: per-phase shader-clock totals accumulated by block 0 of k_lm_step since the last call

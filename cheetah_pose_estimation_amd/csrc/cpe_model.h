@@ -9,6 +9,8 @@
 #define CPE_MAX_SLOTS 320   // structurally non-zero (marker,dof) pairs; 276 for the 25-marker cheetah
 #define CPE_MAX_MCOL 12     // reduced (independent) dofs a marker depends on
 #define CPE_MAX_TERMS 8     // terms of one reduced marker-Jacobian column (1 direct + dependent angles)
+#define CPE_MAX_HG 56        // contributions Dp_i^T M Dp_j one lane gathers into its entries of H (cheetah: ~21)
+#define CPE_MAX_GG 32        // markers one reduced dof can move
 #define CPE_MAX_DEP 32      // dependent angles (26)
 #define CPE_MAX_SCOL 8      // columns of one row of S = d(dependent)/d(independent)
 #define CPE_MAX_SDYN 48     // dynamic (alpha-dependent) body-frame vectors of the leg markers
@@ -62,10 +64,18 @@ struct DevModel {
     int32_t mcol[CPE_MAX_MARKERS][CPE_MAX_MCOL];
     int32_t mcol_off[CPE_MAX_MARKERS + 1];                 // prefix sum of mcol_n
     int32_t term_n[CPE_MAX_MARKERS][CPE_MAX_MCOL];
-    int16_t term_slot[CPE_MAX_MARKERS][CPE_MAX_MCOL][CPE_MAX_TERMS];
-    int16_t term_s[CPE_MAX_MARKERS][CPE_MAX_MCOL][CPE_MAX_TERMS];
+    alignas(16) int16_t term_slot[CPE_MAX_MARKERS][CPE_MAX_MCOL][CPE_MAX_TERMS];     // one 16-byte load per column
+    alignas(16) int16_t term_s[CPE_MAX_MARKERS][CPE_MAX_MCOL][CPE_MAX_TERMS];
     // flat task list over all (marker, reduced column) pairs
     int32_t mc_total;
+    // gather form of H = sum_l Dp_l^T M_l Dp_l (lower triangle, mirrored on store) and g = sum_l Dp_l^T v_l: every lane
+    // owns a balanced set of entries and sums their contributions in a register -- no read-modify-write of H in LDS,
+    // no per-marker synchronisation.  hg_code = ci | cj << 8 | marker << 16 | first-of-entry << 21 | (a << 5 | b) << 22 with
+    // ci, cj = reduced-column indices into Dp and (a, b) the entry of H the contribution belongs to; lane-interleaved.
+    int32_t hg_cnt[64], hg_max;
+    uint32_t hg_code[CPE_MAX_HG][64];
+    int32_t gg_cnt[CPE_NX];
+    uint16_t gg_code[CPE_MAX_GG][CPE_NX];             // ci | marker << 8
     int16_t mc_marker[CPE_MAX_MARKERS * CPE_MAX_MCOL];
     int16_t mc_j[CPE_MAX_MARKERS * CPE_MAX_MCOL];
 

@@ -36,4 +36,11 @@ if hasattr(h.lib, "cpe_debug_lm_stamps"):
     tot = sum(z) or 1
     names = ["accept/reduce", "init rows", "chol", "trsm", "update+Lwrite", "store_row", "bwd partial", "bwd subst+storeL", "dot products", "q update", "row dense", "row motion", "s12", "s13", "s14", "s15"]
     print("k_lm_step phase shares (block 0, last solve):", ", ".join(f"{n} {100.0 * z[i] / tot:.1f}%" for i, n in enumerate(names)), f" total cycles/launch {tot / max(its + 1, 1):.3g}")
+if hasattr(h.lib, "cpe_debug_fn_stamps"):
+    import ctypes as C
+    z = (C.c_ulonglong * 16)()
+    h.lib.cpe_debug_fn_stamps(z)
+    tot = sum(z) or 1
+    names = ["load+sincos+trunk R+leg euler+dyn", "hooke S rows", "positions", "slot dp + Dp", "pairs", "H accumulate", "bounds", "gmm", "write out"]
+    print("k_frame_normal phase shares (block 0):", ", ".join(f"{n} {100.0 * z[i] / tot:.1f}%" for i, n in enumerate(names)))
 print(f"{os.path.basename(args.lib or 'libcpe.so'):28s} B={args.B} iters={its:.1f} total {el*1e3:8.2f} ms  per-iteration {el*1e3/max(its,1):7.3f} ms  cost0 {stats[0].cost:.6g}")
