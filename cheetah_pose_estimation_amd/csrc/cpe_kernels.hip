@@ -183,25 +183,35 @@ __global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevM
     const long wstride = (long)gridDim.x * NW;
     long f = (long)blockIdx.x * NW + wave;
 
-    // q of the NEXT frame is prefetched one frame ahead (it is needed at once); measurements and the three
-    // predecessor q's are loaded at the top of their own frame and consumed late, so their latency is covered.
+    // One drain point per frame.  vmcnt counts loads and stores together and the two kinds may retire out of order with
+    // respect to each other, so with stores in flight the only safe wait for a load is vmcnt(0) -- which drains every
+    // outstanding store of the wave.  The first version waited for its measurements inside each projection pass and for
+    // the next q at the frame end: 4 drains per frame, compute and the 26 KB of J stores never overlapped (compute-only
+    // 1.86 ms + store-only 2.0 ms ~ 3.1 ms measured).  Now a frame issues all its loads at the top, computes everything
+    // (projections and G included) without touching them, waits ONCE, and only then issues its 34 stores in one burst;
+    // the burst drains while the next frame computes.
+    const double2* meas2 = reinterpret_cast<const double2*>(meas);
     double qreg = 0.0;
     if (f < F && lane < nq) qreg = q[f * nq + lane];
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) before the loop: its header then carries no pending load on either edge
 
     while (f < F) {
         if (lane < nq) sq[lane] = qreg;
         const long fn = f + wstride;
+        const bool has_prev = (int)(f % N) >= 3;
         double qn = 0.0, qp1 = 0.0, qp2 = 0.0, qp3 = 0.0;
         double2 mz[NPASS];
-        const bool has_prev = (int)(f % N) >= 3;
+        double wz[NPASS];
         if (lane < nq) {
+            const double* qf = q + f * nq + lane;
             if (fn < F) qn = q[fn * nq + lane];
-            if (has_prev) { const double* qf = q + f * nq + lane; qp1 = qf[-nq]; qp2 = qf[-2 * nq]; qp3 = qf[-3 * nq]; }
+            if (has_prev) { qp1 = qf[-nq]; qp2 = qf[-2 * nq]; qp3 = qf[-3 * nq]; }
         }
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
             const int t = lane + WAVE * p;
-            if (t < CL) mz[p] = reinterpret_cast<const double2*>(meas)[f * CL + t];
+            mz[p] = make_double2(0.0, 0.0); wz[p] = 0.0;
+            if (t < CL) { mz[p] = meas2[f * CL + t]; if (WANT_COST) wz[p] = weight[f * CL + t]; }
         }
         wave_lds_sync();
         wave_sincos(M, sq, ssc, lane);
@@ -242,46 +252,58 @@ __global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevM
         }
         wave_lds_sync();        // R, sincos, q are dead from here: G may overlay them
 
-        // project every (camera, marker) pair: residual out, d(u,v)/dp to LDS.  The J rows of a camera are
-        // stored as soon as all its pairs are projected, so the 26 KB of stores per frame are spread over the
-        // projection passes instead of arriving in one burst.
-        // J[c][s][0..1] = G_{c,marker(s)} . dp_s : 16-byte stores, consecutive lanes -> consecutive slots
+        // project every (camera, marker) pair: (u, v) stay in registers, d(u,v)/dp goes to LDS; nothing is stored yet
         const long pair0 = f * CL;
         double2* Jf = reinterpret_cast<double2*>(J) + f * (long)(C * S);
         double fc = 0.0;
-        int c_done = 0;
+        double2 uv[NPASS];
 #pragma unroll
         for (int p = 0; p < NPASS; p++) {
             __builtin_amdgcn_sched_barrier(0);      // keep the passes sequential: interleaving them costs ~40 VGPRs
             const int t = lane + WAVE * p;
+            uv[p] = make_double2(0.0, 0.0);
             if (t < CL) {
                 const int c = t / L, l = t - c * L;
                 double u, v, G[6];
                 project_point(cams[c], spos[3 * l], spos[3 * l + 1], spos[3 * l + 2], u, v, G);
-                const double e0 = u - mz[p].x, e1 = v - mz[p].y;
-                reinterpret_cast<double2*>(r)[pair0 + t] = make_double2(e0, e1);
+                uv[p] = make_double2(u, v);
                 double2* Gd = reinterpret_cast<double2*>(sG + 6 * t);
                 Gd[0] = make_double2(G[0], G[1]); Gd[1] = make_double2(G[2], G[3]); Gd[2] = make_double2(G[4], G[5]);
+            }
+        }
+        wave_lds_sync();
+        // the frame's only wait on vector memory: this frame's loads have arrived, the previous frame's stores have drained
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // the loaded values become usable HERE: without this the compiler hoists 3*qp1, 3*qp2 to the top of the frame and
+        // waits for them there (which drains the previous frame's stores at once)
+        asm volatile("" : "+v"(qp1), "+v"(qp2), "+v"(qp3), "+v"(qn));
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            const int t = lane + WAVE * p;
+            if (t < CL) {
+                const double e0 = uv[p].x - mz[p].x, e1 = uv[p].y - mz[p].y;
+                reinterpret_cast<double2*>(r)[pair0 + t] = make_double2(e0, e1);
                 if (WANT_COST) {
-                    const double w = cams[c].mult * weight[pair0 + t];
+                    const double w = cams[t / L].mult * wz[p];
                     fc += robust_loss(w * e0, la, lb, lc, 0, false).rho + robust_loss(w * e1, la, lb, lc, 0, false).rho;
                 }
             }
-            wave_lds_sync();
-            const int c_now = p == NPASS - 1 ? C : min(C, (WAVE * (p + 1)) / L);
-            for (int c = c_done; c < c_now; c++) {
+        }
+        // J[c][s][0..1] = G_{c,marker(s)} . dp_s : 16-byte streaming stores, consecutive lanes -> consecutive slots
+        for (int c = 0; c < C; c++) {
 #pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    const int s = lane + WAVE * i;
-                    if (s < S) {
-                        const double2* G = reinterpret_cast<const double2*>(sG + 6 * (c * L + mk[i]));
-                        const double2 g0 = G[0], g1 = G[1], g2 = G[2];
-                        Jf[c * S + s] = make_double2(g0.x * dp0[i] + g0.y * dp1[i] + g1.x * dp2[i],
-                                                     g1.y * dp0[i] + g2.x * dp1[i] + g2.y * dp2[i]);
-                    }
+            for (int i = 0; i < 5; i++) {
+                const int s = lane + WAVE * i;
+                if (s < S) {
+                    const double2* G = reinterpret_cast<const double2*>(sG + 6 * (c * L + mk[i]));
+                    const double2 g0 = G[0], g1 = G[1], g2 = G[2];
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    v2d val;
+                    val.x = g0.x * dp0[i] + g0.y * dp1[i] + g1.x * dp2[i];
+                    val.y = g1.y * dp0[i] + g2.x * dp1[i] + g2.y * dp2[i];
+                    __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(&Jf[c * S + s]));
                 }
             }
-            c_done = c_now;
         }
         if (WANT_COST) {
             fc = wave_sum(fc);
