@@ -407,3 +407,25 @@ def test_error_behaviour_of_the_abi(sk25, cams6, gpu_handle_factory):
         _lib.Handle(skeleton.build_skeleton("phantom", 24), cams6, None, pr)
     with pytest.raises(_lib.CpeError):
         _lib.Handle(sk25, cams6, device=99)
+
+
+@pytest.mark.parametrize("C", [1, 2, 8])
+def test_resjac_other_camera_counts(C, oracle, gpu_handle_factory):
+    """1 and 2 cameras (a single projection pass) and 8 cameras x 25 markers = 200 pairs (the 4-pass instantiation of
+    k_resjac), with and without the cost output"""
+    sk = skeleton.build_skeleton("phantom", 25)
+    cams = synth.make_cameras(C)
+    h = gpu_handle_factory(sk, cams)
+    d = synth.make_batch(sk, cams, B=2, N=9, seed=21)
+    q = d["q_true"] + np.random.default_rng(6).normal(0, 0.03, d["q_true"].shape)
+    sm, sd = h.jacobian_layout()
+    opts = abi.default_options()
+    for want_cost in (True, False):
+        r, J, eps, cost = h.eval_resjac_host(q, d["meas"], d["weight"], want_cost=want_cost)
+        for b in range(2):
+            ro, Jo, eo, co = oracle.eval_resjac(sk, cams, opts, q[b], d["meas"][b], d["weight"][b])
+            assert np.abs(r[b] - ro).max() < 1e-8 * max(1.0, np.abs(ro).max())
+            assert np.abs(_dense_from_slots(J[b], sm, sd, 25, sk.nq) - Jo).max() < 1e-9 * np.abs(Jo).max()
+            assert np.abs(eps[b] - eo).max() < 1e-9 * max(1.0, np.abs(eo).max())
+            if want_cost:
+                assert np.abs(cost[b] - co).max() < 1e-9 * np.abs(co).max()
