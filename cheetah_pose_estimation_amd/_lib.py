@@ -70,6 +70,7 @@ def load():
     lib.cpe_eval_normal.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
+    lib.cpe_grf_fit.argtypes = [vp, C.POINTER(abi.GrfOptions), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     _LIB = lib
     return lib
 
@@ -87,7 +88,7 @@ def _ptr(t):
     if isinstance(t, np.ndarray):
         assert t.dtype == np.float64 and t.flags["C_CONTIGUOUS"]
         return t.ctypes.data
-    assert t.dtype.is_floating_point and t.element_size() == 8 and t.is_contiguous()
+    assert t.is_contiguous() and ((t.dtype.is_floating_point and t.element_size() == 8) or str(t.dtype) == "torch.int32")
     return t.data_ptr()
 
 
@@ -163,6 +164,24 @@ class Handle:
                                 _ptr(positions), _ptr(meas_err), stats)
         _check(st, "cpe_solve", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
         return st, list(stats)[:B]
+
+    def grf_fit(self, gopt, q, dq, ddq, contact, grfz, grfxy, residual=None):
+        """per-frame ground-reaction-force fit (device tensors); contact int32 [B, N, n_feet]"""
+        _check(self.lib.cpe_grf_fit(self._h, C.byref(gopt), q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(ddq), _ptr(contact),
+                                    _ptr(grfz), _ptr(grfxy), _ptr(residual)), "cpe_grf_fit")
+
+    def grf_fit_host(self, gopt, q, dq, ddq, contact):
+        """numpy in, numpy out (staged through HBM with torch): grfz [B, N, nf], grfxy [B, N, nf, 4], residual [B, N, 6]"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        T = lambda a, dt: torch.tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+        qd, dqd, ddqd, cd = T(q, np.float64), T(dq, np.float64), T(ddq, np.float64), T(contact, np.int32)
+        B, N, nf = qd.shape[0], qd.shape[1], gopt.n_feet
+        gz = torch.empty((B, N, nf), dtype=torch.float64, device=dev); gxy = torch.empty((B, N, nf, 4), dtype=torch.float64, device=dev)
+        res = torch.empty((B, N, 6), dtype=torch.float64, device=dev)
+        self.grf_fit(gopt, qd, dqd, ddqd, cd, gz, gxy, res)
+        self.synchronize()
+        return gz.cpu().numpy(), gxy.cpu().numpy(), res.cpu().numpy()
 
     # ---- host-pointer conveniences (numpy in, numpy out; PCIe-inclusive) -------------------------------
     def eval_resjac_host(self, q, meas, weight, want_cost=True):

@@ -84,6 +84,15 @@ class Stats(C.Structure):
     ]
 
 
+class GrfOptions(C.Structure):
+    """mirror of cpe_grf_options (include/cpe.h)"""
+    _fields_ = [
+        ("root_inertia", C.c_double * 3), ("friction_ratio", C.c_double), ("force_max", C.c_double),
+        ("regularisation", C.c_double), ("gravity", C.c_double),
+        ("n_feet", C.c_int32), ("foot_marker", C.c_int32 * 4), ("iterations", C.c_int32),
+    ]
+
+
 def default_options(fps: float = 120.0) -> Options:
     """Same defaults as cpe_default_options() in csrc/cpe_api.cpp."""
     o = Options()

@@ -472,6 +472,22 @@ cpe_status cpe_project_joints(cpe_handle* h, int32_t B, int32_t N, double* q) {
     return fl ? CPE_NUMERICAL : CPE_OK;
 }
 
+cpe_status cpe_grf_fit(cpe_handle* h, const cpe_grf_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
+                       const double* ddq, const int32_t* contact, double* grfz, double* grfxy, double* residual) {
+    if (!h || !opt || !q || !dq || !ddq || !contact || !grfz || !grfxy) return fail(CPE_BAD_ARG, "null argument");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    if (opt->n_feet < 1 || opt->n_feet > 4 || opt->iterations < 1 || !(opt->gravity > 0) || !(opt->force_max > 0) || !(opt->friction_ratio >= 0))
+        return fail(CPE_BAD_ARG, "grf options out of range");
+    for (int f = 0; f < opt->n_feet; f++)
+        if (opt->foot_marker[f] < 0 || opt->foot_marker[f] >= h->hm.L) return fail(CPE_BAD_ARG, "foot marker index out of range");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_grf, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, *opt, F, q, dq, ddq, contact, grfz, grfxy, residual);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
 cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q, double* positions, double* com) {
     if (!h || !q || !positions) return fail(CPE_BAD_ARG, "null argument");
     const size_t F = (size_t)B * N;

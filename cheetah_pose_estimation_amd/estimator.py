@@ -273,6 +273,41 @@ class CheetahEstimator:
         rel = np.where(ref < 0, q, sgn * (q - q[..., np.maximum(ref, 0)]))
         return rel[..., ind]
 
+    def estimate_grf(self, plot: bool = False, monocular: bool = False, out_dir_prefix: Optional[str] = None,
+                     contacts: Optional[dict] = None):
+        """Per-frame ground-reaction-force fit, same signature and return value as CheetahEstimator.estimate_grf
+        (acinoset_opt.py:176-270): reads the kinematic result `fte_kinematic[_<cam>]/fte.pickle` and the contact windows of
+        `grf/autogen-contact.json` (written by the reference's determine_contacts; may be passed as `contacts` instead),
+        fits the forces of the feet in contact on the GPU (cpe_grf_fit) and returns ({foot: [GRFz per frame]},
+        {foot: [[4 friction components] per frame]}) in body weights."""
+        params, scene, sk = self.params, self.scene, self.skeleton
+        data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, self.data_path)
+        sub = "fte_kinematic" if not monocular else f"fte_kinematic_{scene.cam_idx}"
+        with open(os.path.join(data_dir, sub, "fte.pickle"), "rb") as fh:          # written by CheetahEstimator.save above
+            fte = pickle.load(fh)
+        if contacts is None:
+            with open(os.path.join(data_dir, "grf", "autogen-contact.json"), "r", encoding="utf-8") as fh:
+                contacts = json.load(fh)
+        start_frame, end_frame = contacts["start_frame"], contacts["end_frame"]
+        N = end_frame - start_frame
+        feet = [f"{name}_foot" for name in skeleton.FEET]
+        flags = np.zeros((N, len(feet)), np.int32)
+        for i, f in enumerate(feet):
+            for a, b in (contacts["contacts"].get(f) or []):
+                lo, hi = max(a - start_frame, 0), min(b - start_frame, N)
+                if hi > lo:
+                    flags[lo:hi, i] = 1
+        gopt = skeleton.grf_options(self.name)                                # load_params falls back to the generic animal
+        h = _lib.Handle(sk, self.cams, device=self.device)
+        try:
+            gz, gxy, res = h.grf_fit_host(gopt, fte["q"][None, :N], fte["dq"][None, :N], fte["ddq"][None, :N], flags[None])
+        finally:
+            h.close()
+        self.grf_residual = res[0]
+        grfz_est = {f: [float(v) for v in gz[0, :, i]] for i, f in enumerate(feet)}
+        grfxy_est = {f: [[float(v) for v in row] for row in gxy[0, :, i]] for i, f in enumerate(feet)}
+        return grfz_est, grfxy_est
+
     def save(self, out_dir: str, fname: str = "fte", out_dir_prefix: Optional[str] = None):
         """fte.pickle + cam*_fte.csv, acinoset_opt.py:278-373."""
         res, params, scene = self.result, self.params, self.scene
@@ -425,4 +460,5 @@ def estimate_kinetics(estimator, *args, **kwargs) -> bool:
 
 
 def estimate_grf(estimator, *args, **kwargs) -> bool:
-    raise NotImplementedError("per-frame GRF fit (acinoset_opt.py:966-1048): SURVEY 8 row a13, not built yet")
+    raise NotImplementedError("GRF re-optimisation of the kinetic trajectory (acinoset_opt.py:966-1048) belongs to the physics-based "
+                              "model, SURVEY 8 row a12, not built; the per-frame fit (row a13) is CheetahEstimator.estimate_grf")

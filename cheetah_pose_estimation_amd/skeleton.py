@@ -221,3 +221,23 @@ def jacobian_layout(sk: abi.Skeleton):
         sm += [l] * len(dofs)
         sd += dofs
     return np.array(sm, dtype=np.int32), np.array(sd, dtype=np.int32)
+
+
+FEET = ("HFL", "HFR", "HBL", "HBR")                   # pe.foot.feet(robot): add_foot(hock, at="bottom") in link order (cheetah.py:104)
+FOOT_MARKERS = ("l_front_paw", "r_front_paw", "l_back_paw", "r_back_paw")
+
+
+def grf_options(animal: str = "phantom", iterations: int = 2000) -> abi.GrfOptions:
+    """Options of the per-frame GRF fit (acinoset_opt.py:176-270): feet = hock bottoms = the paw markers, root inertia =
+    solid cylinder along the body axis x (I_axis = m r^2 / 2, I_perp = m L^2 / 12 + m r^2 / 4)."""
+    p = load_params(animal)["body_B"]
+    m, L, r = p["mass"], p["length"], p["radius"]
+    o = abi.GrfOptions()
+    o.root_inertia[0] = 0.5 * m * r * r
+    o.root_inertia[1] = o.root_inertia[2] = m * L * L / 12.0 + 0.25 * m * r * r
+    o.friction_ratio, o.force_max, o.regularisation, o.gravity = 1.3, 5.0, 1e-6, 9.81
+    o.n_feet = 4
+    for i, name in enumerate(FOOT_MARKERS):
+        o.foot_marker[i] = MARKERS.index(name)
+    o.iterations = iterations
+    return o

@@ -198,6 +198,32 @@ cpe_status cpe_solve_host(cpe_handle* h, int32_t B, int32_t N, const double* q_i
                           const double* weight, double* q, double* dq, double* ddq, double* positions,
                           double* meas_err, cpe_stats* stats);
 
+/* ---- per-frame ground-reaction-force fit (CheetahEstimator.estimate_grf, acinoset_opt.py:176-270).
+ * Rows 0-5 (root x, y, z, phi, theta, psi) of d/dt dL/dq' - dL/dq for L = sum_i (m_i |P_i'|^2 / 2 + w_i^T I_i w_i / 2
+ * - m_i g P_i,z) are balanced against B = sum_feet (d foot / dq)^T M g (GRFz e_z + sum_k D_k GRFxy_k),
+ * D = [+x, +y, -x, -y], for the feet flagged in contact:  minimise |rows - B| subject to 0 <= GRF <= force_max and
+ * friction_ratio * GRFz >= sum_k GRFxy_k per foot (acinoset_opt.py:183-192).  Forces are in body weights (M g).
+ * The reference hands each frame to IPOPT; the least-squares problem is convex but not strictly (opposing friction
+ * components, three or more feet), so IPOPT's answer is one point of a face of minimisers.  Here the face is resolved
+ * by the minimum-norm minimiser (Tikhonov term `regularisation`), computed by FISTA with exact projections, a fixed
+ * `iterations` count, identically in oracle and HIP.  Only the root link's inertia enters rows 0-5 (all other
+ * orientations are independent coordinates). */
+typedef struct cpe_grf_options {
+    double root_inertia[3];   /* principal moments of the root link about its body axes (cheetah: cylinder along x)   */
+    double friction_ratio;    /* 1.3 (acinoset_opt.py:190)                                                            */
+    double force_max;         /* 5.0 (acinoset_opt.py:186-187)                                                        */
+    double regularisation;    /* 1e-6                                                                                 */
+    double gravity;           /* 9.81                                                                                 */
+    int32_t n_feet;           /* <= 4                                                                                 */
+    int32_t foot_marker[4];   /* marker sitting at hock.bottom of each foot (the paw markers), order = output order   */
+    int32_t iterations;       /* FISTA iterations (2000)                                                              */
+} cpe_grf_options;
+
+/* q, dq, ddq [B][N][nq]; contact [B][N][n_feet] (0 / 1); grfz [B][N][n_feet]; grfxy [B][N][n_feet][4];
+ * residual [B][N][6] = rows - B at the solution, in units of M g (may be NULL).  Device pointers. */
+cpe_status cpe_grf_fit(cpe_handle* h, const cpe_grf_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
+                       const double* ddq, const int32_t* contact, double* grfz, double* grfxy, double* residual);
+
 /* forward kinematics only (get_pose_state / get_com, acinoset_misc.py:1581-1659, :722-742); device ptrs */
 cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q,
                                   double* positions /*[B][N][L][3]*/, double* com /*[B][N][3] or NULL*/);

@@ -954,6 +954,124 @@ void cpo_move_coordinate(const cpe_skeleton* s, int N, double* q, int n, int k, 
     memcpy(q + (size_t)n * x.nq, st, sizeof(double) * x.nq);
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* per-frame ground-reaction-force fit (acinoset_opt.py:176-270); see include/cpe.h        */
+/* ------------------------------------------------------------------------------------------------ */
+static void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* body-frame angular velocity / acceleration of a link from its ZYX Euler angles, rates and accelerations */
+static void body_rates(const double* a, const double* da, const double* dda, double* w, double* al, double Jw[3][3]) {
+    double sf = sin(a[0]), cf = cos(a[0]), st = sin(a[1]), ct = cos(a[1]);
+    /* columns of d w / d(phi', theta', psi') */
+    double c0[3] = {1, 0, 0}, c1[3] = {0, cf, -sf}, c2[3] = {-st, sf * ct, cf * ct};
+    double d1[3] = {0, -sf * da[0], -cf * da[0]};
+    double d2[3] = {-ct * da[1], cf * da[0] * ct - sf * st * da[1], -sf * da[0] * ct - cf * st * da[1]};
+    for (int k = 0; k < 3; k++) {
+        w[k] = c0[k] * da[0] + c1[k] * da[1] + c2[k] * da[2];
+        al[k] = c0[k] * dda[0] + c1[k] * dda[1] + c2[k] * dda[2] + d1[k] * da[1] + d2[k] * da[2];
+        if (Jw) { Jw[k][0] = c0[k]; Jw[k][1] = c1[k]; Jw[k][2] = c2[k]; }
+    }
+}
+/* rows 0-5 of the equations of motion, E[6], and the force matrix A[6][5 n_feet] (columns per foot: z, +x, +y, -x, -y),
+ * both divided by M g */
+void cpo_grf_terms(const cpe_skeleton* s, const cpe_grf_options* o, const double* q, const double* dq, const double* ddq,
+                   double* E, double* A) {
+    int nl = s->n_links, nf = o->n_feet, nv = 5 * nf;
+    double R[CPE_MAX_LINKS * 9], w[CPE_MAX_LINKS][3], al[CPE_MAX_LINKS][3], oacc[CPE_MAX_LINKS][3], first[CPE_MAX_LINKS][3];
+    double Jw[3][3], M = 0, g = o->gravity;
+    int root = -1;
+    for (int i = 0; i < nl; i++) {
+        cpo_rot(q + 3 + 3 * i, R + 9 * i);
+        body_rates(q + 3 + 3 * i, dq + 3 + 3 * i, ddq + 3 + 3 * i, w[i], al[i], s->parent[i] < 0 ? Jw : NULL);
+        M += s->mass[i];
+        if (s->parent[i] < 0) root = i;
+    }
+    double dRr[3][9];
+    cpo_drot(q + 3 + 3 * root, dRr);
+    for (int k = 0; k < 6; k++) E[k] = 0;
+    for (int k = 0; k < 6 * nv; k++) A[k] = 0;
+    /* acceleration of a body-fixed vector v of link i: R (w x (w x v) + alpha x v) */
+#define POINT_ACC(i, v, out) do { double t1[3], t2[3], t3[3]; cross3(w[i], v, t1); cross3(w[i], t1, t2); cross3(al[i], v, t3); \
+        for (int d_ = 0; d_ < 3; d_++) t2[d_] += t3[d_]; matvec3(R + 9 * (i), t2, out); } while (0)
+    for (int i = 0; i < nl; i++) {                       /* parents precede children in the link order */
+        int p = s->parent[i];
+        if (p < 0) { for (int d = 0; d < 3; d++) { oacc[i][d] = ddq[d]; first[i][d] = s->com[i][d]; } }
+        else {
+            double a3[3]; POINT_ACC(p, s->attach[i], a3);
+            for (int d = 0; d < 3; d++) { oacc[i][d] = oacc[p][d] + a3[d]; first[i][d] = p == root ? s->attach[i][d] : first[p][d]; }
+        }
+        double ac[3]; POINT_ACC(i, s->com[i], ac);
+        double f[3] = {s->mass[i] * (oacc[i][0] + ac[0]), s->mass[i] * (oacc[i][1] + ac[1]), s->mass[i] * (oacc[i][2] + ac[2] + g)};
+        for (int d = 0; d < 3; d++) E[d] += f[d];
+        for (int a = 0; a < 3; a++) { double v[3]; matvec3(dRr[a], first[i], v); E[3 + a] += f[0] * v[0] + f[1] * v[1] + f[2] * v[2]; }
+    }
+    {   /* rotation of the root link itself */
+        const double* I = o->root_inertia;
+        double Iw[3] = {I[0] * w[root][0], I[1] * w[root][1], I[2] * w[root][2]}, wIw[3];
+        cross3(w[root], Iw, wIw);
+        double tq[3] = {I[0] * al[root][0] + wIw[0], I[1] * al[root][1] + wIw[1], I[2] * al[root][2] + wIw[2]};
+        for (int a = 0; a < 3; a++) E[3 + a] += tq[0] * Jw[0][a] + tq[1] * Jw[1][a] + tq[2] * Jw[2][a];
+    }
+    static const double D[5][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, -1, 0}};
+    for (int f = 0; f < nf; f++) {
+        int lk = s->marker_link[o->foot_marker[f]];
+        for (int k = 0; k < 5; k++) {
+            int col = 5 * f + k;
+            for (int d = 0; d < 3; d++) A[d * nv + col] = D[k][d];
+            for (int a = 0; a < 3; a++) {
+                double v[3]; matvec3(dRr[a], lk == root ? s->marker_off[o->foot_marker[f]] : first[lk], v);
+                A[(3 + a) * nv + col] = v[0] * D[k][0] + v[1] * D[k][1] + v[2] * D[k][2];
+            }
+        }
+    }
+    for (int k = 0; k < 6; k++) E[k] /= M * g;
+#undef POINT_ACC
+}
+
+/* projection of y0[5] = (z, x0..x3) onto {0 <= . <= fmax, sum x <= mu z}: clamp(y0 - lam n), n = (-mu, 1, 1, 1, 1), lam >= 0 by bisection */
+static void grf_project(double* y, double mu, double fmax) {
+    double y0[5]; memcpy(y0, y, sizeof(y0));
+    double lo = 0, hi = 0;
+#define CL(v) ((v) < 0 ? 0 : ((v) > fmax ? fmax : (v)))
+#define GFUN(l) (CL(y0[1] - (l)) + CL(y0[2] - (l)) + CL(y0[3] - (l)) + CL(y0[4] - (l)) - mu * CL(y0[0] + mu * (l)))
+    if (GFUN(0.0) > 0) {
+        hi = y0[1];                                   /* at lam = max_k x_k every x is clamped to 0: g <= 0 */
+        for (int k = 2; k < 5; k++) if (y0[k] > hi) hi = y0[k];
+        for (int it = 0; it < 50; it++) { double mid = 0.5 * (lo + hi); if (GFUN(mid) > 0) lo = mid; else hi = mid; }
+    }
+    y[0] = CL(y0[0] + mu * hi);
+    for (int k = 1; k < 5; k++) y[k] = CL(y0[k] - hi);
+#undef GFUN
+#undef CL
+}
+
+/* one frame: forces y[5 n_feet] (z, +x, +y, -x, -y per foot), residual res[6] (units of M g) */
+void cpo_grf_fit_frame(const cpe_skeleton* s, const cpe_grf_options* o, const double* q, const double* dq, const double* ddq,
+                       const int32_t* contact, double* y, double* res) {
+    int nf = o->n_feet, nv = 5 * nf;
+    double E[6], A[6 * 20], v[20], yp[20], gr[20];
+    cpo_grf_terms(s, o, q, dq, ddq, E, A);
+    double L = o->regularisation; int any = 0;
+    for (int f = 0; f < nf; f++) if (contact[f]) { any = 1; for (int k = 0; k < 5; k++) for (int r = 0; r < 6; r++) L += A[r * nv + 5 * f + k] * A[r * nv + 5 * f + k]; }
+    for (int c = 0; c < nv; c++) { y[c] = 0; v[c] = 0; }
+    if (any)
+        for (int it = 0; it < o->iterations; it++) {
+            double r6[6];
+            for (int r = 0; r < 6; r++) { double a = E[r]; for (int c = 0; c < nv; c++) a -= A[r * nv + c] * v[c]; r6[r] = a; }
+            for (int c = 0; c < nv; c++) { double a = o->regularisation * v[c]; for (int r = 0; r < 6; r++) a -= A[r * nv + c] * r6[r]; gr[c] = a; }
+            memcpy(yp, y, sizeof(double) * nv);
+            for (int f = 0; f < nf; f++) {
+                if (!contact[f]) { for (int k = 0; k < 5; k++) y[5 * f + k] = 0; continue; }
+                for (int k = 0; k < 5; k++) y[5 * f + k] = v[5 * f + k] - gr[5 * f + k] / L;
+                grf_project(y + 5 * f, o->friction_ratio, o->force_max);
+            }
+            double beta = (double)it / (double)(it + 3);
+            for (int c = 0; c < nv; c++) v[c] = y[c] + beta * (y[c] - yp[c]);
+        }
+    if (res) for (int r = 0; r < 6; r++) { double a = E[r]; for (int c = 0; c < nv; c++) a -= A[r * nv + c] * y[c]; res[r] = a; }
+}
+
 void cpo_default_options(cpe_options* o) {
     o->h = 1.0 / 120; o->loss_a = 3; o->loss_b = 10; o->loss_c = 20; o->cost_scale = 1e-3;
     o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-3; o->tol_step = 1e-8; o->tol_cost = 1e-12;

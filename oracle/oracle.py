@@ -190,3 +190,23 @@ def frame_normal(sk, cams, opts, priors, q, meas, weight):
     lib().cpo_frame_normal(C.byref(sk), cams, weight.shape[0], C.byref(opts), C.byref(priors) if priors is not None else None,
                            _p(q), _p(meas), _p(weight), _p(g), _p(Bm), _p(cost), _p(Z))
     return g, Bm, cost, Z, q
+
+
+def grf_terms(sk, gopt, q, dq, ddq):
+    """rows 0-5 of the equations of motion E[6] and the force matrix A[6, 5 n_feet], both in units of M g"""
+    nv = 5 * gopt.n_feet
+    E = np.empty(6); A = np.empty((6, nv))
+    lib().cpo_grf_terms(C.byref(sk), C.byref(gopt), _p(_c(q)), _p(_c(dq)), _p(_c(ddq)), _p(E), _p(A))
+    return E, A
+
+
+def grf_fit(sk, gopt, q, dq, ddq, contact):
+    """per-frame GRF fit of a whole trajectory: grfz [N, n_feet], grfxy [N, n_feet, 4], residual [N, 6]"""
+    q, dq, ddq = _c(q), _c(dq), _c(ddq)
+    contact = np.ascontiguousarray(contact, dtype=np.int32)
+    N, nf = q.shape[0], gopt.n_feet
+    y = np.empty((N, nf, 5)); res = np.empty((N, 6))
+    for n in range(N):
+        lib().cpo_grf_fit_frame(C.byref(sk), C.byref(gopt), _p(q[n]), _p(dq[n]), _p(ddq[n]),
+                                contact[n].ctypes.data_as(C.c_void_p), _p(y[n]), _p(res[n]))
+    return y[:, :, 0].copy(), y[:, :, 1:].copy(), res

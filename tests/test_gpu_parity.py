@@ -168,6 +168,21 @@ def test_estimator_api_end_to_end_from_files(tmp_path, oracle):
     got = rows[:, 1:].reshape(30, 24, 3)[:, :, :2]
     ok = np.isfinite(got)
     assert np.abs(got[ok] - uv[ok]).max() < 1e-9
+    # per-frame GRF fit from the files just written (CheetahEstimator.estimate_grf, acinoset_opt.py:176-270) with the contact
+    # windows a determine_contacts run would have left in grf/autogen-contact.json
+    contacts = {"start_frame": 4, "end_frame": 24, "contacts": {"HFL_foot": [[6, 12]], "HFR_foot": [[9, 15]], "HBL_foot": None, "HBR_foot": [[4, 8], [18, 24]]}}
+    os.makedirs(os.path.join(est.params.data_dir, "grf"), exist_ok=True)
+    with open(os.path.join(est.params.data_dir, "grf", "autogen-contact.json"), "w") as fh:
+        import json
+        json.dump(contacts, fh)
+    grfz, grfxy = est.estimate_grf()
+    assert sorted(grfz) == ["HBL_foot", "HBR_foot", "HFL_foot", "HFR_foot"] and all(len(v) == 20 for v in grfz.values())
+    assert max(grfz["HBL_foot"]) == 0 and grfz["HFL_foot"][0] == 0 and max(grfz["HFL_foot"][2:8]) > 0
+    assert all(len(row) == 4 for row in grfxy["HFR_foot"]) and est.grf_residual.shape == (20, 6)
+    gopt = skeleton.grf_options(est.name)
+    flags = np.zeros((20, 4), np.int32); flags[2:8, 0] = 1; flags[5:11, 1] = 1; flags[0:4, 3] = 1; flags[14:20, 3] = 1
+    oz, oxy, _ = oracle.grf_fit(est.skeleton, gopt, d["q"][:20], d["dq"][:20], d["ddq"][:20], flags)
+    assert np.abs(np.array([grfz[f"{n}_foot"] for n in skeleton.FEET]).T - oz).max() < 1e-8
 
 
 def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_factory):
@@ -429,3 +444,29 @@ def test_resjac_other_camera_counts(C, oracle, gpu_handle_factory):
             assert np.abs(eps[b] - eo).max() < 1e-9 * max(1.0, np.abs(eo).max())
             if want_cost:
                 assert np.abs(cost[b] - co).max() < 1e-9 * np.abs(co).max()
+
+
+def test_grf_fit_matches_oracle(oracle, gpu_handle_factory):
+    """per-frame ground-reaction-force fit (acinoset_opt.py:176-270) on a solved-like trajectory: rows of
+    the equations of motion, forces and residual, HIP vs oracle (same FISTA iteration, same projection)."""
+    sk = skeleton.build_skeleton("phantom", 24)
+    cams = synth.make_cameras(2)
+    gopt = skeleton.grf_options("phantom", iterations=800)
+    h = gpu_handle_factory(sk, cams)
+    N = 24
+    d = synth.make_batch(sk, cams, B=2, N=N, seed=17)
+    q = d["q_true"]
+    dq = np.zeros_like(q); ddq = np.zeros_like(q)
+    for b in range(2):
+        dq[b], ddq[b] = oracle.derivatives(q[b], 1.0 / 120.0)
+    rng = np.random.default_rng(4)
+    contact = (rng.random((2, N, 4)) < 0.5).astype(np.int32)
+    contact[0, 0] = 0                                                       # a flight frame
+    contact[0, 1] = 1                                                       # all four feet down
+    gz, gxy, res = h.grf_fit_host(gopt, q, dq, ddq, contact)
+    for b in range(2):
+        oz, oxy, ores = oracle.grf_fit(sk, gopt, q[b], dq[b], ddq[b], contact[b])
+        assert np.abs(ores - res[b]).max() < 1e-8 and np.abs(oz - gz[b]).max() < 1e-8 and np.abs(oxy - gxy[b]).max() < 1e-8
+        assert (gz[b] >= 0).all() and (gz[b] <= 5).all() and (gxy[b].sum(-1) <= 1.3 * gz[b] + 1e-9).all()
+        assert np.abs(gz[b][contact[b] == 0]).max() == 0
+    assert np.abs(gz[0, 0]).max() == 0 and gz[0, 1].sum() > 0.1

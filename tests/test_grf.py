@@ -1,0 +1,101 @@
+"""Per-frame ground-reaction-force fit (acinoset_opt.py:176-270).  CPU: the oracle's rows 0-5 of the
+equations of motion against an independent numerical Lagrangian (numpy finite differences of T and V along a smooth
+trajectory), properties of the fit.  The reference's lambdified rows live in dill pickles (`models/*_grf_eom`) that the
+permitted loaders refuse and `pe.foot` is absent, so versus the reference this row is "parity unpinned"; the formula
+follows SURVEY A.8, which reports 1e-13 agreement with those functions."""
+import numpy as np
+import pytest
+
+from cheetah_pose_estimation_amd import abi, skeleton, synth
+
+
+def _traj(sk, t):
+    """smooth analytic trajectory q(t) (every angle of every link moves)"""
+    k = np.arange(sk.nq)
+    return 0.3 * np.sin(1.7 * t + 0.37 * k) + 0.1 * np.cos(3.1 * t + 0.11 * k * k) + np.where(k < 3, 2.0 * t, 0.0)
+
+
+def _omega_body(a, da):
+    sf, cf, st, ct = np.sin(a[0]), np.cos(a[0]), np.sin(a[1]), np.cos(a[1])
+    return np.array([da[0] - st * da[2], cf * da[1] + sf * ct * da[2], -sf * da[1] + cf * ct * da[2]])
+
+
+def _rot_c(ang):
+    """rot_zyx for complex angles (complex-step differentiation)"""
+    sf, cf, st, ct, sp, cp = np.sin(ang[0]), np.cos(ang[0]), np.sin(ang[1]), np.cos(ang[1]), np.sin(ang[2]), np.cos(ang[2])
+    return np.array([[cp * ct, sf * st * cp - sp * cf, sf * sp + st * cf * cp],
+                     [sp * ct, sf * sp * st + cf * cp, -sf * cp + sp * st * cf],
+                     [-st, sf * ct, cf * ct]])
+
+
+def _lagrangian(sk, gopt, q, dq):
+    """L = sum_i (m_i |P_i'|^2 / 2 - m_i g P_i,z) + w_root^T I w_root / 2; the rotational energy of the other links does not
+    depend on the root coordinates and drops out of rows 0-5.  P_i' = d/ds P_i(q + s dq) exactly, by the complex step."""
+    def coms(qq):
+        R = [_rot_c(qq[3 + 3 * i:6 + 3 * i]) for i in range(sk.n_links)]
+        origin, out = [None] * sk.n_links, []
+        for i in range(sk.n_links):
+            origin[i] = qq[:3] if sk.parent[i] < 0 else origin[sk.parent[i]] + R[sk.parent[i]] @ np.array(sk.attach[i][:])
+            out.append(origin[i] + R[i] @ np.array(sk.com[i][:]))
+        return np.array(out)
+    cs = coms(q + 1e-30j * dq)
+    P, V = cs.real, cs.imag / 1e-30
+    m = np.array(sk.mass[:sk.n_links])
+    w = _omega_body(q[3:6], dq[3:6])
+    I = np.array(gopt.root_inertia[:])
+    return 0.5 * (m * (V ** 2).sum(1)).sum() - gopt.gravity * (m * P[:, 2]).sum() + 0.5 * (I * w * w).sum()
+
+
+def test_eom_rows_match_a_numerical_lagrangian(oracle):
+    sk = skeleton.build_skeleton("phantom", 24)
+    gopt = skeleton.grf_options("phantom")
+    M = sum(sk.mass[:sk.n_links])
+    ht = 1e-4
+    for t0 in (0.3, 1.1):
+        qf = lambda t: _traj(sk, t)
+        q = qf(t0)
+        dq = (qf(t0 + ht) - qf(t0 - ht)) / (2 * ht)
+        ddq = (qf(t0 + ht) - 2 * q + qf(t0 - ht)) / ht ** 2
+        E, A = oracle.grf_terms(sk, gopt, q, dq, ddq)
+
+        def dL_ddq(t, a):       # dL/dq'_a at time t
+            qq = qf(t); dd = (qf(t + ht) - qf(t - ht)) / (2 * ht)
+            e = np.zeros(sk.nq); e[a] = 1.0                      # L is quadratic in q': the central difference is exact
+            return (_lagrangian(sk, gopt, qq, dd + e) - _lagrangian(sk, gopt, qq, dd - e)) / 2.0
+
+        for a in range(6):
+            ddt = (dL_ddq(t0 + 1e-3, a) - dL_ddq(t0 - 1e-3, a)) / 2e-3
+            e = np.zeros(sk.nq); e[a] = 1e-6
+            dLdq = (_lagrangian(sk, gopt, q + e, dq) - _lagrangian(sk, gopt, q - e, dq)) / 2e-6
+            ref = (ddt - dLdq) / (M * gopt.gravity)
+            assert abs(E[a] - ref) < 2e-6 * max(1.0, abs(ref)), (a, E[a], ref)
+    # the force matrix: d foot / d(root coordinates), by finite differences of the marker positions
+    pos0 = oracle.markers(sk, q)
+    for a in range(6):
+        e = np.zeros(sk.nq); e[a] = 1e-6
+        dp = (oracle.markers(sk, q + e) - oracle.markers(sk, q - e)) / 2e-6
+        D = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, -1, 0.0]])
+        for f in range(4):
+            for k in range(5):
+                assert abs(A[a, 5 * f + k] - dp[gopt.foot_marker[f]] @ D[k]) < 1e-8
+
+
+def test_standing_still_carries_the_body_weight(oracle):
+    """at rest with all four feet down the vertical forces sum to one body weight, friction vanishes, moments balance"""
+    sk = skeleton.build_skeleton("phantom", 24)
+    gopt = skeleton.grf_options("phantom", iterations=4000)
+    d = synth.make_batch(sk, synth.make_cameras(1), B=1, N=1, seed=3)
+    q = d["q_true"][0]
+    z = np.zeros_like(q)
+    grfz, grfxy, res = oracle.grf_fit(sk, gopt, q, z, z, np.ones((1, 4), np.int32))
+    assert abs(grfz.sum() - 1.0) < 1e-4 and np.abs(res).max() < 1e-4
+    assert grfxy.max() < 0.05 and grfz.min() >= 0                     # the minimum-norm tie-break spreads a little friction
+    net = grfxy[0].sum(0)
+    assert abs(net[0] - net[2]) < 1e-4 and abs(net[1] - net[3]) < 1e-4   # no net horizontal force at rest
+    # flight phase: no contact -> no force, the residual is the unbalanced weight
+    grfz, grfxy, res = oracle.grf_fit(sk, gopt, q, z, z, np.zeros((1, 4), np.int32))
+    assert grfz.max() == 0 and abs(res[0, 2] - 1.0) < 1e-12
+    # one foot cannot balance the moments: constraints hold, residual stays
+    c = np.zeros((1, 4), np.int32); c[0, 2] = 1
+    grfz, grfxy, res = oracle.grf_fit(sk, gopt, q, z, z, c)
+    assert (grfxy[0, 2].sum() <= 1.3 * grfz[0, 2] + 1e-9) and grfz[0, [0, 1, 3]].max() == 0 and 0 <= grfz[0, 2] <= 5
