@@ -470,3 +470,16 @@ def test_grf_fit_matches_oracle(oracle, gpu_handle_factory):
         assert (gz[b] >= 0).all() and (gz[b] <= 5).all() and (gxy[b].sum(-1) <= 1.3 * gz[b] + 1e-9).all()
         assert np.abs(gz[b][contact[b] == 0]).max() == 0
     assert np.abs(gz[0, 0]).max() == 0 and gz[0, 1].sum() > 0.1
+
+
+def test_solve_long_sequence(sk25, cams6, oracle, gpu_handle_factory):
+    """N = 450 frames (more than twice the benchmark length): the sliding window, the factor columns in HBM and the frame-major
+    buffers scale with N; same minimiser as the oracle"""
+    opts = abi.default_options()
+    h = gpu_handle_factory(sk25, cams6, opts)
+    d = synth.make_batch(sk25, cams6, B=1, N=450, seed=123)
+    out = h.solve_host(d["q_init"], d["meas"], d["weight"])
+    ref = oracle.solve(sk25, cams6, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+    assert out["stats"][0].status == ref["stats"].status == abi.OK
+    assert abs(out["stats"][0].cost - ref["stats"].cost) < 1e-7 * ref["stats"].cost
+    assert np.sqrt(((out["positions"][0] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-4
