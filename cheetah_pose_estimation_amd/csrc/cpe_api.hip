@@ -326,22 +326,12 @@ void cpe_default_options(cpe_options* o) {
     o->curvature = 0; o->max_outer = 8; o->_pad = 0;
 }
 
-cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts,
-                      const cpe_priors* priors, int32_t device, cpe_handle** out) {
-    if (!skel || !cams || !opts || !out) return fail(CPE_BAD_ARG, "null argument");
-    const bool use_pri = priors && (priors->gmm_k > 0 || priors->lr_window > 0);
-    if (use_pri) {
-        if (priors->gmm_k < 0 || priors->gmm_k > CPE_MAX_GMM || priors->gmm_dim < 0 || priors->gmm_dim > CPE_NX || (priors->gmm_k > 0 && priors->gmm_dim < 1))
-            return fail(CPE_BAD_ARG, "pose prior: component count / dimension out of range");
-        if (priors->lr_window < 0 || priors->lr_window > CPE_MAX_WINDOW) return fail(CPE_BAD_ARG, "motion prior: window out of range");
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CPE_NO_DEVICE, "no HIP device: this library has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(CPE_BAD_ARG, "device index out of range");
-    cpe_handle* h = new cpe_handle();
-    h->device = device; h->opts = *opts;
+void cpe_destroy(cpe_handle* h);
+static cpe_status create_impl(cpe_handle* h, const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts,
+                              const cpe_priors* priors, bool use_pri) {
+    const int device = h->device;
     cpe_status s = build_model(skel, cams, n_cams, opts, h->hm);
-    if (s != CPE_OK) { delete h; return s; }
+    if (s != CPE_OK) return s;
     HIPCHK(hipSetDevice(device));
     {
         hipDeviceProp_t prop;
@@ -385,6 +375,25 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
         h->gmm_k = priors->gmm_k; h->gmm_dim = priors->gmm_dim; h->lr_window = W;
         h->pb = W > 3 ? W : 3;
     }
+    return CPE_OK;
+}
+
+cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams, const cpe_options* opts,
+                      const cpe_priors* priors, int32_t device, cpe_handle** out) {
+    if (!skel || !cams || !opts || !out) return fail(CPE_BAD_ARG, "null argument");
+    const bool use_pri = priors && (priors->gmm_k > 0 || priors->lr_window > 0);
+    if (use_pri) {
+        if (priors->gmm_k < 0 || priors->gmm_k > CPE_MAX_GMM || priors->gmm_dim < 0 || priors->gmm_dim > CPE_NX || (priors->gmm_k > 0 && priors->gmm_dim < 1))
+            return fail(CPE_BAD_ARG, "pose prior: component count / dimension out of range");
+        if (priors->lr_window < 0 || priors->lr_window > CPE_MAX_WINDOW) return fail(CPE_BAD_ARG, "motion prior: window out of range");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CPE_NO_DEVICE, "no HIP device: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(CPE_BAD_ARG, "device index out of range");
+    cpe_handle* h = new cpe_handle();
+    h->device = device; h->opts = *opts;
+    const cpe_status s = create_impl(h, skel, cams, n_cams, opts, priors, use_pri);
+    if (s != CPE_OK) { cpe_destroy(h); return s; }      // releases whatever was allocated before the failure
     *out = h;
     return CPE_OK;
 }
