@@ -34,7 +34,7 @@ if hasattr(h.lib, "cpe_debug_lm_stamps"):
     z = (C.c_ulonglong * 16)()
     h.lib.cpe_debug_lm_stamps(z)
     tot = sum(z) or 1
-    names = ["accept/reduce", "init rows", "chol", "trsm", "update+Lwrite", "store_row", "bwd partial", "bwd subst+storeL", "dot products", "q update", "row dense", "row motion", "s12", "s13", "s14", "s15"]
+    names = ["accept/reduce", "init rows", "chol", "trsm", "update+Lwrite", "store_row", "bwd partial", "bwd subst+storeL", "dot products", "q update", "row dense", "row motion", "bwd subst (thread 0 view)", "bwd wait for L prefetch + LDS store", "s14", "s15"]
     print("k_lm_step phase shares (block 0, last solve):", ", ".join(f"{n} {100.0 * z[i] / tot:.1f}%" for i, n in enumerate(names)), f" total cycles/launch {tot / max(its + 1, 1):.3g}")
 if hasattr(h.lib, "cpe_debug_fn_stamps"):
     import ctypes as C
