@@ -293,7 +293,8 @@ class CheetahEstimator:
         feet = [f"{name}_foot" for name in skeleton.FEET]
         flags = np.zeros((N, len(feet)), np.int32)
         for i, f in enumerate(feet):
-            for a, b in (contacts["contacts"].get(f) or []):
+            for seq in (contacts["contacts"].get(f) or []):           # [first, last, foot index, "leading"|"trailing"] (acinoset_misc.py:812)
+                a, b = int(seq[0]), int(seq[1])
                 lo, hi = max(a - start_frame, 0), min(b - start_frame, N)
                 if hi > lo:
                     flags[lo:hi, i] = 1

@@ -170,7 +170,7 @@ def test_estimator_api_end_to_end_from_files(tmp_path, oracle):
     assert np.abs(got[ok] - uv[ok]).max() < 1e-9
     # per-frame GRF fit from the files just written (CheetahEstimator.estimate_grf, acinoset_opt.py:176-270) with the contact
     # windows a determine_contacts run would have left in grf/autogen-contact.json
-    contacts = {"start_frame": 4, "end_frame": 24, "contacts": {"HFL_foot": [[6, 12]], "HFR_foot": [[9, 15]], "HBL_foot": None, "HBR_foot": [[4, 8], [18, 24]]}}
+    contacts = {"start_frame": 4, "end_frame": 24, "contacts": {"HFL_foot": [[6, 12, 0, "trailing"]], "HFR_foot": [[9, 15, 1, "leading"]], "HBL_foot": None, "HBR_foot": [[4, 8, 3, "TBD"], [18, 24, 3, "TBD"]]}}
     os.makedirs(os.path.join(est.params.data_dir, "grf"), exist_ok=True)
     with open(os.path.join(est.params.data_dir, "grf", "autogen-contact.json"), "w") as fh:
         import json
