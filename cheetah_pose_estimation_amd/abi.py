@@ -102,7 +102,7 @@ def default_options(fps: float = 120.0) -> Options:
     o.bound_penalty = 1e4
     o.bound_tol = 1e-6
     o.max_outer = 8
-    o.lambda0 = 1e-3
+    o.lambda0 = 1e-4
     o.tol_step = 1e-8
     o.tol_cost = 1e-12
     o.max_iter = 200

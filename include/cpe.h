@@ -116,7 +116,7 @@ typedef struct cpe_options {
     double cost_scale;   /* 1e-3 (acinoset_opt.py:602); only scales the reported objective      */
     double bound_penalty;/* kappa of the augmented Lagrangian that enforces the 23 angle bounds   */
     double bound_tol;    /* bounds are met when the largest violation is below this (rad)         */
-    double lambda0;      /* initial Levenberg-Marquardt damping                                 */
+    double lambda0;      /* initial Levenberg-Marquardt damping (default 1e-4)                  */
     double tol_step;     /* converged when max |du| < tol_step                                  */
     double tol_cost;     /* ... or relative cost decrease < tol_cost                            */
     int32_t max_iter;

@@ -267,6 +267,8 @@ def test_solve_through_the_gimbal_region(cams6, oracle, gpu_handle_factory):
     sk = skeleton.build_skeleton("phantom", 25)
     sk.n_bounds = 0
     opts = abi.default_options()
+    opts.lambda0 = 1e-3        # conservative start: with the default 1e-4 the first steps through this exaggerated swing are large
+    #                            enough for round-off to send the two implementations into neighbouring minima (costs 0.07 % apart)
     h = gpu_handle_factory(sk, cams6, opts)
     d = synth.make_batch(sk, cams6, B=2, N=24, seed=61, wide_limbs=True)
     near = d["q_true"] + np.random.default_rng(0).normal(0, 0.01, d["q_true"].shape)
@@ -383,8 +385,8 @@ def test_solve_short_sequences(N, sk25, cams6, oracle, gpu_handle_factory):
         st, rs = out["stats"][b], ref["stats"]
         assert st.status in (abi.OK, abi.MAX_ITER) and np.isfinite(out["q"][b]).all()
         # whatever path was taken, the reported cost is the oracle's objective at the returned trajectory
-        f = oracle.objective(sk25, cams6, opts, None, out["q"][b], d["meas"][b], d["weight"][b])[0]
-        assert abs(st.cost - opts.cost_scale * f) < 1e-7 * abs(st.cost)
+        terms = oracle.objective(sk25, cams6, opts, None, out["q"][b], d["meas"][b], d["weight"][b])[3]
+        assert abs(st.cost - opts.cost_scale * (terms[0] + terms[1])) < 1e-9 * abs(st.cost)     # measurement + model (the bound term is not part of obj_cost)
         assert abs(st.cost - rs.cost) < 0.1 * abs(rs.cost)                 # neighbouring minima of the redescending loss at worst
         if rs.iterations < 80 and st.iterations < 80 and abs(st.iterations - rs.iterations) <= 1:
             quick += 1
