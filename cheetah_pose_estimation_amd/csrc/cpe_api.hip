@@ -595,9 +595,13 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
             if (!running) break;
         }
     }
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, Fw, h->qbuf, meas, q, dq, ddq, positions, meas_err);
+    HIPCHK(hipMemsetAsync(h->cmax, 0, sizeof(double) * B, h->stream));
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, Fw, h->qbuf, meas, q, dq, ddq, positions, meas_err,
+                       reinterpret_cast<unsigned long long*>(h->cmax));
     HIPCHK(hipGetLastError());
+    std::vector<double> hc(B);
     HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hc.data(), h->cmax, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     cpe_status worst = CPE_OK;
     for (int b = 0; b < B; b++) {
@@ -606,7 +610,7 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
         if (sb > worst) worst = sb;
         if (stats) {
             cpe_stats& o = stats[b];
-            o.status = sb; o.iterations = S.iters; o.lambda = S.lambda; o.max_constraint = 0.0;
+            o.status = sb; o.iterations = S.iters; o.lambda = S.lambda; o.max_constraint = hc[b];
             o.max_bound_violation = S.maxviol; o.outer = S.outer; o._pad = 0;
             o.cost_meas = S.terms[0]; o.cost_model = S.terms[1]; o.cost_pose = S.terms[3]; o.cost_motion = S.terms[4];
             o.cost = h->opts.cost_scale * (S.terms[0] + S.terms[1] + S.terms[3] + S.terms[4]);

@@ -112,6 +112,7 @@ def test_solve_matches_oracle_within_1mm(sk25, cams6, oracle, gpu_handle_factory
         assert np.abs(out["meas_err"][b] - ref["meas_err"]).max() < 1e-2
         c = np.array([np.abs(oracle.constraints(sk25, x)).max() for x in out["q"][b]])
         assert c.max() < 1e-12
+        assert abs(st.max_constraint - c.max()) < 1e-15                # the device reports the same number
         dq, ddq = oracle.derivatives(out["q"][b], opts.h)
         assert np.abs(out["dq"][b] - dq).max() < 1e-6 * max(1, np.abs(dq).max())
         assert np.abs(out["ddq"][b] - ddq).max() < 1e-6 * max(1, np.abs(ddq).max())
