@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2048, help="sequences per GPU for the residual+Jacobian pass")
-    ap.add_argument("--solve-batch", type=int, default=512, help="sequences per GPU for the solve timing")
+    ap.add_argument("--solve-batch", type=int, default=2048, help="sequences per GPU for the solve timing")
     ap.add_argument("--markers", type=int, default=25)
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true")

@@ -33,6 +33,7 @@ struct cpe_handle {
            *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr, *gambuf = nullptr;
     SeqState* st = nullptr;
     int* flag = nullptr;
+    int* act = nullptr;          // [ws_B] sequences of the current launch window
     // learned priors (config 3)
     DevPriors* pri = nullptr;    // device copy, nullptr without priors
     int gmm_k = 0, gmm_dim = 0, lr_window = 0;
@@ -399,9 +400,9 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
 }
 
 static void free_ws(cpe_handle* h) {
-    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st, h->Hlr};
+    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st, h->Hlr, h->act};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = h->Hlr = nullptr; h->st = nullptr;
+    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = h->Hlr = nullptr; h->st = nullptr; h->act = nullptr;
     h->ws_frames = 0; h->ws_B = 0;
 }
 
@@ -523,6 +524,7 @@ static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     HIPCHK(hipMalloc(&h->gtbuf, sizeof(double) * F * nu));
     HIPCHK(hipMalloc(&h->cmax, sizeof(double) * F));
     HIPCHK(hipMalloc(&h->st, sizeof(SeqState) * B));
+    HIPCHK(hipMalloc(&h->act, sizeof(int) * B));
     if (h->lr_window > 0) HIPCHK(hipMalloc(&h->Hlr, sizeof(double) * 2 * F * h->pb * nu * nu));
     h->ws_frames = F; h->ws_B = B;
     return CPE_OK;
@@ -543,7 +545,7 @@ cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q,
     HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
-                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr);
     HIPCHK(hipMemcpyAsync(g, h->gbuf, sizeof(double) * F * m.nu, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(Bm, h->Bbuf, sizeof(double) * F * m.nu * m.nu, hipMemcpyDeviceToDevice, h->stream));
     hipLaunchKernelGGL(k_gather_normal, dim3((unsigned)F), dim3(128), 0, h->stream, h->dm, F, h->qbuf, h->costbuf, h->gambuf, cost, gam, q_out);
@@ -572,28 +574,46 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;
     const size_t ldsn = lds_normal(m, h->gmm_k, h->gmm_dim);
     const bool lr = h->lr_window > 0;
-    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
-    if (lr) hipLaunchKernelGGL(k_lr_band, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->st, N, 1, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf, h->Hlr, h->costbuf);
-    auto lm_step = [&](int first) {
-        if (h->pb == 3) hipLaunchKernelGGL(k_lm_step<3>, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr);
-        else hipLaunchKernelGGL(k_lm_step<4>, dim3(B), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr);
+    // One LM iteration = k_frame_normal (+ k_lr_band) on the evaluated buffer, then k_lm_step, for the sequences listed in `act`
+    // (device int array, nullptr = all B).
+    auto iterate = [&](int first, const int* act, int n_act) {
+        const unsigned gf = (unsigned)((size_t)n_act * N);
+        hipLaunchKernelGGL(k_frame_normal, dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
+                           h->costbuf, h->mu, h->gambuf, h->pri, act);
+        if (lr) hipLaunchKernelGGL(k_lr_band, dim3(gf), dim3(WAVE), 0, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf,
+                                   h->Hlr, h->costbuf, act);
+        if (h->pb == 3) hipLaunchKernelGGL(k_lm_step<3>, dim3(n_act), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
+                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act);
+        else hipLaunchKernelGGL(k_lm_step<4>, dim3(n_act), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
+                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act);
     };
-    lm_step(1);
+    iterate(1, nullptr, B);                 // first evaluation and first step of every sequence
     HIPCHK(hipGetLastError());
+    // Active window: k_lm_step runs one workgroup per sequence and its duration is the sequential depth of ONE sequence,
+    // whatever the grid (3.3 ms for <= 256 workgroups, 4.4 ms for 512 = 2 per CU), so the launches are kept exactly full: the first
+    // `window` unfinished sequences iterate, the list is rebuilt every POLL iterations from the status words, and a
+    // sequence that converges hands its slot to the next waiting one instead of idling until the slowest of its batch ends.
     std::vector<SeqState> hs(B);
-    const int rounds = h->opts.max_iter + 2 * (h->opts.max_outer > 0 ? h->opts.max_outer : 0);   // a multiplier update costs one extra round
-    for (int it = 0; it < rounds; it++) {
-        hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri);
-        if (lr) hipLaunchKernelGGL(k_lr_band, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->st, N, 0, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf, h->Hlr, h->costbuf);
-        lm_step(0);
-        if ((it & 7) == 7 || it == rounds - 1) {
+    std::vector<int> act_h;
+    const int window = h->n_cu * (h->pb == 3 ? 2 : 1);
+    constexpr int POLL = 4;                 // small launches: poll every 4th iteration; large ones (>= 16k frames, several ms) every iteration
+    const long per_seq = (long)h->opts.max_iter + 2L * (h->opts.max_outer > 0 ? h->opts.max_outer : 0) + POLL;
+    const long max_rounds = ((long)(B + window - 1) / window + 1) * per_seq;
+    int n_act = 0;
+    long next_poll = 0;
+    for (long it = 0; it < max_rounds; it++) {
+        if (it >= next_poll) {
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            bool running = false;
-            for (int b = 0; b < B; b++) running |= hs[b].status == 0;
-            if (!running) break;
+            act_h.clear();
+            for (int b = 0; b < B && (int)act_h.size() < window; b++) if (hs[b].status == 0) act_h.push_back(b);
+            n_act = (int)act_h.size();
+            if (n_act == 0) break;
+            HIPCHK(hipMemcpyAsync(h->act, act_h.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, h->stream));
+            next_poll = it + ((size_t)n_act * N >= 16384 ? 1 : POLL);
         }
+        iterate(0, h->act, n_act);
     }
     HIPCHK(hipMemsetAsync(h->cmax, 0, sizeof(double) * B, h->stream));
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, Fw, h->qbuf, meas, q, dq, ddq, positions, meas_err,
