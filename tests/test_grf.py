@@ -99,3 +99,18 @@ def test_standing_still_carries_the_body_weight(oracle):
     c = np.zeros((1, 4), np.int32); c[0, 2] = 1
     grfz, grfxy, res = oracle.grf_fit(sk, gopt, q, z, z, c)
     assert (grfxy[0, 2].sum() <= 1.3 * grfz[0, 2] + 1e-9) and grfz[0, [0, 1, 3]].max() == 0 and 0 <= grfz[0, 2] <= 5
+
+
+def test_free_fall_needs_no_force(oracle):
+    """a rigid, non-rotating body in free fall: every row of the equations of motion vanishes (sign and scale of gravity),
+    and a body held still needs exactly one body weight along z"""
+    sk = skeleton.build_skeleton("phantom", 24)
+    gopt = skeleton.grf_options("phantom")
+    d = synth.make_batch(sk, synth.make_cameras(1), B=1, N=1, seed=9)
+    q = d["q_true"][0, 0]
+    dq = np.zeros_like(q); dq[0] = 3.0; dq[2] = -1.5                       # translating, not rotating
+    ddq = np.zeros_like(q); ddq[2] = -gopt.gravity
+    E, _ = oracle.grf_terms(sk, gopt, q, dq, ddq)
+    assert np.abs(E).max() < 1e-12
+    E, _ = oracle.grf_terms(sk, gopt, q, np.zeros_like(q), np.zeros_like(q))
+    assert abs(E[2] - 1.0) < 1e-12 and np.abs(E[:2]).max() < 1e-12
