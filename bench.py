@@ -153,7 +153,7 @@ def main():
         del r, J, eps
         q = torch.empty((Bs, N, sk.nq), dtype=torch.float64, device=dev); dq = torch.empty_like(q); ddq = torch.empty_like(q)
         pos = torch.empty((Bs, N, L, 3), dtype=torch.float64, device=dev); me = torch.empty((Bs, N, C, L, 2), dtype=torch.float64, device=dev)
-        h.solve(ts_["q_init"][:8].contiguous(), ts_["meas"][:8].contiguous(), ts_["weight"][:8].contiguous(), q[:8], dq[:8], ddq[:8], pos[:8], me[:8])   # warm-up
+        h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)   # warm-up at full size: the solver workspace (16 GB for 2048 sequences) is allocated here
         barrier()
         t1 = time.perf_counter()
         st, stats = h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)
