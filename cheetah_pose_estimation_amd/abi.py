@@ -93,6 +93,11 @@ class GrfOptions(C.Structure):
     ]
 
 
+class EomOptions(C.Structure):
+    """mirror of cpe_eom_options (include/cpe.h)"""
+    _fields_ = [("gravity", C.c_double), ("link_inertia", d3 * MAX_LINKS)]
+
+
 def default_options(fps: float = 120.0) -> Options:
     """Same defaults as cpe_default_options() in csrc/cpe_api.cpp."""
     o = Options()

@@ -34,6 +34,7 @@ struct cpe_handle {
     SeqState* st = nullptr;
     int* flag = nullptr;
     int* act = nullptr;          // [ws_B] sequences of the current launch window
+    cpe_eom_options* eom = nullptr;   // device copy of the last cpe_eom_rows options
     // learned priors (config 3)
     DevPriors* pri = nullptr;    // device copy, nullptr without priors
     int gmm_k = 0, gmm_dim = 0, lr_window = 0;
@@ -413,6 +414,7 @@ void cpe_destroy(cpe_handle* h) {
     if (h->dm) (void)hipFree(h->dm);
     if (h->flag) (void)hipFree(h->flag);
     if (h->pri) (void)hipFree(h->pri);
+    if (h->eom) (void)hipFree(h->eom);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -494,6 +496,20 @@ cpe_status cpe_grf_fit(cpe_handle* h, const cpe_grf_options* opt, int32_t B, int
     if (F == 0) return CPE_OK;
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_grf, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, *opt, F, q, dq, ddq, contact, grfz, grfxy, residual);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
+cpe_status cpe_eom_rows(cpe_handle* h, const cpe_eom_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
+                        const double* ddq, double* rows) {
+    if (!h || !opt || !q || !dq || !ddq || !rows) return fail(CPE_BAD_ARG, "null argument");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->eom) HIPCHK(hipMalloc(&h->eom, sizeof(cpe_eom_options)));
+    HIPCHK(hipMemcpyAsync(h->eom, opt, sizeof(cpe_eom_options), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_eom, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->eom, F, q, dq, ddq, rows);
     HIPCHK(hipGetLastError());
     return CPE_OK;
 }

@@ -241,3 +241,21 @@ def grf_options(animal: str = "phantom", iterations: int = 2000) -> abi.GrfOptio
         o.foot_marker[i] = MARKERS.index(name)
     o.iterations = iterations
     return o
+
+
+def eom_options(animal: str = "phantom") -> abi.EomOptions:
+    """gravity and the principal moments of every link: solid cylinders (I_axis = m r^2 / 2,
+    I_perp = m L^2 / 12 + m r^2 / 4) along the link's aligned axis -- x for the trunk and tail links, z for the leg links
+    (cheetah.py:19-200)."""
+    p = load_params(animal)
+    o = abi.EomOptions()
+    o.gravity = 9.81
+    for i, name in enumerate(LINKS):
+        lp = _link_param(p, name)
+        m, L, r = lp["mass"], lp["length"], lp["radius"]
+        ax, perp = 0.5 * m * r * r, m * L * L / 12.0 + 0.25 * m * r * r
+        along_x = name in ("base", "bodyF", "neck", "tail0", "tail1")
+        o.link_inertia[i][0] = ax if along_x else perp
+        o.link_inertia[i][1] = perp
+        o.link_inertia[i][2] = perp if along_x else ax
+    return o

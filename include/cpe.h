@@ -224,6 +224,21 @@ typedef struct cpe_grf_options {
 cpe_status cpe_grf_fit(cpe_handle* h, const cpe_grf_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
                        const double* ddq, const int32_t* contact, double* grfz, double* grfxy, double* residual);
 
+/* ---- all rows of the equations of motion (the residual function of the physics-based model, config 4 / SURVEY row a12:
+ * `make_pyomo_model(include_eom_slack=True)`, acinoset_opt.py:510-514): rows [B][N][nq] = d/dt dL/dq' - dL/dq in N and N m for
+ * L = sum_i (m_i |P_i'|^2 / 2 + w_i^T I_i w_i / 2 - m_i g P_i,z), evaluated from (q, q', q'') without forming M, C, G:
+ * row of angle a of link i = f_i . (dR_i/da c_i) + sum over the children c of i  F_subtree(c) . (dR_i/da attach_c)
+ *                            + (I_i alpha_i + w_i x I_i w_i) . dw_i/dq'_a,     f_j = m_j (P_j'' + g e_z).
+ * What the reference balances these rows against (motor torques, the 26 joint constraint forces, contact forces, slack) is
+ * not built yet; this is the evaluation kernel those terms will be added to.  link_inertia: principal moments of every link
+ * about its body axes.  Device pointers. */
+typedef struct cpe_eom_options {
+    double gravity;
+    double link_inertia[CPE_MAX_LINKS][3];
+} cpe_eom_options;
+cpe_status cpe_eom_rows(cpe_handle* h, const cpe_eom_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
+                        const double* ddq, double* rows);
+
 /* forward kinematics only (get_pose_state / get_com, acinoset_misc.py:1581-1659, :722-742); device ptrs */
 cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q,
                                   double* positions /*[B][N][L][3]*/, double* com /*[B][N][3] or NULL*/);

@@ -1030,6 +1030,46 @@ void cpo_grf_terms(const cpe_skeleton* s, const cpe_grf_options* o, const double
 #undef POINT_ACC
 }
 
+/* all nq rows of d/dt dL/dq' - dL/dq (include/cpe.h, cpe_eom_rows) */
+void cpo_eom_rows(const cpe_skeleton* s, const cpe_eom_options* o, const double* q, const double* dq, const double* ddq, double* E) {
+    int nl = s->n_links;
+    double R[CPE_MAX_LINKS * 9], w[CPE_MAX_LINKS][3], al[CPE_MAX_LINKS][3], oacc[CPE_MAX_LINKS][3], f[CPE_MAX_LINKS][3], Fs[CPE_MAX_LINKS][3];
+    double Jw[CPE_MAX_LINKS][3][3], g = o->gravity;
+    for (int i = 0; i < nl; i++) {
+        cpo_rot(q + 3 + 3 * i, R + 9 * i);
+        body_rates(q + 3 + 3 * i, dq + 3 + 3 * i, ddq + 3 + 3 * i, w[i], al[i], Jw[i]);
+    }
+#define POINT_ACC(i, v, out) do { double t1[3], t2[3], t3[3]; cross3(w[i], v, t1); cross3(w[i], t1, t2); cross3(al[i], v, t3); \
+        for (int d_ = 0; d_ < 3; d_++) t2[d_] += t3[d_]; matvec3(R + 9 * (i), t2, out); } while (0)
+    for (int i = 0; i < nl; i++) {
+        int p = s->parent[i];
+        if (p < 0) for (int d = 0; d < 3; d++) oacc[i][d] = ddq[d];
+        else { double a3[3]; POINT_ACC(p, s->attach[i], a3); for (int d = 0; d < 3; d++) oacc[i][d] = oacc[p][d] + a3[d]; }
+        double ac[3]; POINT_ACC(i, s->com[i], ac);
+        for (int d = 0; d < 3; d++) { f[i][d] = s->mass[i] * (oacc[i][d] + ac[d] + (d == 2 ? g : 0.0)); Fs[i][d] = f[i][d]; }
+    }
+#undef POINT_ACC
+    for (int i = nl - 1; i >= 0; i--) if (s->parent[i] >= 0) for (int d = 0; d < 3; d++) Fs[s->parent[i]][d] += Fs[i][d];
+    for (int i = 0; i < nl; i++) {
+        if (s->parent[i] < 0) for (int d = 0; d < 3; d++) E[d] = Fs[i][d];
+        double dR[3][9];
+        cpo_drot(q + 3 + 3 * i, dR);
+        const double* I = o->link_inertia[i];
+        double Iw[3] = {I[0] * w[i][0], I[1] * w[i][1], I[2] * w[i][2]}, wIw[3];
+        cross3(w[i], Iw, wIw);
+        double tq[3] = {I[0] * al[i][0] + wIw[0], I[1] * al[i][1] + wIw[1], I[2] * al[i][2] + wIw[2]};
+        for (int a = 0; a < 3; a++) {
+            double v[3], e;
+            matvec3(dR[a], s->com[i], v);
+            e = f[i][0] * v[0] + f[i][1] * v[1] + f[i][2] * v[2];
+            for (int c = 0; c < nl; c++)
+                if (s->parent[c] == i) { matvec3(dR[a], s->attach[c], v); e += Fs[c][0] * v[0] + Fs[c][1] * v[1] + Fs[c][2] * v[2]; }
+            e += tq[0] * Jw[i][0][a] + tq[1] * Jw[i][1][a] + tq[2] * Jw[i][2][a];
+            E[3 + 3 * i + a] = e;
+        }
+    }
+}
+
 /* projection of y0[5] = (z, x0..x3) onto {0 <= . <= fmax, sum x <= mu z}: clamp(y0 - lam n), n = (-mu, 1, 1, 1, 1), lam >= 0 by bisection */
 static void grf_project(double* y, double mu, double fmax) {
     double y0[5]; memcpy(y0, y, sizeof(y0));

@@ -210,3 +210,10 @@ def grf_fit(sk, gopt, q, dq, ddq, contact):
         lib().cpo_grf_fit_frame(C.byref(sk), C.byref(gopt), _p(q[n]), _p(dq[n]), _p(ddq[n]),
                                 contact[n].ctypes.data_as(C.c_void_p), _p(y[n]), _p(res[n]))
     return y[:, :, 0].copy(), y[:, :, 1:].copy(), res
+
+
+def eom_rows(sk, eopt, q, dq, ddq):
+    """all nq rows of d/dt dL/dq' - dL/dq for one frame"""
+    E = np.empty(sk.nq)
+    lib().cpo_eom_rows(C.byref(sk), C.byref(eopt), _p(_c(q)), _p(_c(dq)), _p(_c(ddq)), _p(E))
+    return E

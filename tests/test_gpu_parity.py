@@ -490,3 +490,26 @@ def test_solve_long_sequence(sk25, cams6, oracle, gpu_handle_factory):
     assert out["stats"][0].status == ref["stats"].status == abi.OK
     assert abs(out["stats"][0].cost - ref["stats"].cost) < 1e-7 * ref["stats"].cost
     assert np.sqrt(((out["positions"][0] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-4
+
+
+def test_eom_rows_match_oracle(oracle, gpu_handle_factory):
+    """all 54 rows of the equations of motion (residual function of the physics-based model), HIP vs oracle"""
+    import torch
+    sk = skeleton.build_skeleton("phantom", 24)
+    eopt = skeleton.eom_options("phantom")
+    h = gpu_handle_factory(sk, synth.make_cameras(1))
+    d = synth.make_batch(sk, synth.make_cameras(1), B=2, N=16, seed=29)
+    q = d["q_true"]
+    dq = np.zeros_like(q); ddq = np.zeros_like(q)
+    for b in range(2):
+        dq[b], ddq[b] = oracle.derivatives(q[b], 1.0 / 120.0)
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    rows = torch.empty((2, 16, sk.nq), dtype=torch.float64, device=dev)
+    h.eom_rows(eopt, T(q), T(dq), T(ddq), rows); h.synchronize()
+    rows = rows.cpu().numpy()
+    scale = sum(sk.mass[:sk.n_links]) * 9.81
+    for b in range(2):
+        for n in range(16):
+            E = oracle.eom_rows(sk, eopt, q[b, n], dq[b, n], ddq[b, n])
+            assert np.abs(rows[b, n] - E).max() < 1e-10 * scale

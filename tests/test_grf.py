@@ -28,7 +28,7 @@ def _rot_c(ang):
                      [-st, sf * ct, cf * ct]])
 
 
-def _lagrangian(sk, gopt, q, dq):
+def _lagrangian(sk, gopt, q, dq, all_inertia=None):
     """L = sum_i (m_i |P_i'|^2 / 2 - m_i g P_i,z) + w_root^T I w_root / 2; the rotational energy of the other links does not
     depend on the root coordinates and drops out of rows 0-5.  P_i' = d/ds P_i(q + s dq) exactly, by the complex step."""
     def coms(qq):
@@ -41,9 +41,13 @@ def _lagrangian(sk, gopt, q, dq):
     cs = coms(q + 1e-30j * dq)
     P, V = cs.real, cs.imag / 1e-30
     m = np.array(sk.mass[:sk.n_links])
-    w = _omega_body(q[3:6], dq[3:6])
-    I = np.array(gopt.root_inertia[:])
-    return 0.5 * (m * (V ** 2).sum(1)).sum() - gopt.gravity * (m * P[:, 2]).sum() + 0.5 * (I * w * w).sum()
+    if all_inertia is not None:                                 # rotational energy of every link (needed for the rows of all angles)
+        rot = sum(0.5 * (np.array(all_inertia[i][:]) * _omega_body(q[3 + 3 * i:6 + 3 * i], dq[3 + 3 * i:6 + 3 * i]) ** 2).sum()
+                  for i in range(sk.n_links))
+    else:
+        w = _omega_body(q[3:6], dq[3:6])
+        rot = 0.5 * (np.array(gopt.root_inertia[:]) * w * w).sum()
+    return 0.5 * (m * (V ** 2).sum(1)).sum() - gopt.gravity * (m * P[:, 2]).sum() + rot
 
 
 def test_eom_rows_match_a_numerical_lagrangian(oracle):
@@ -114,3 +118,34 @@ def test_free_fall_needs_no_force(oracle):
     assert np.abs(E).max() < 1e-12
     E, _ = oracle.grf_terms(sk, gopt, q, np.zeros_like(q), np.zeros_like(q))
     assert abs(E[2] - 1.0) < 1e-12 and np.abs(E[:2]).max() < 1e-12
+
+
+def test_all_eom_rows_match_a_numerical_lagrangian(oracle):
+    """cpo_eom_rows: all 54 rows of d/dt dL/dq' - dL/dq (the residual function of the physics-based model)
+    against finite differences of the Lagrangian with every link's rotational energy"""
+    sk = skeleton.build_skeleton("phantom", 24)
+    eopt = skeleton.eom_options("phantom")
+    gopt = skeleton.grf_options("phantom")
+    assert np.allclose(eopt.link_inertia[0][:], gopt.root_inertia[:])
+    ht, t0 = 1e-4, 0.7
+    qf = lambda t: _traj(sk, t)
+    q = qf(t0)
+    dq = (qf(t0 + ht) - qf(t0 - ht)) / (2 * ht)
+    ddq = (qf(t0 + ht) - 2 * q + qf(t0 - ht)) / ht ** 2
+    E = oracle.eom_rows(sk, eopt, q, dq, ddq)
+    L = lambda qq, dd: _lagrangian(sk, gopt, qq, dd, eopt.link_inertia)
+
+    def dL_ddq(t, a):
+        qq = qf(t); dd = (qf(t + ht) - qf(t - ht)) / (2 * ht)
+        e = np.zeros(sk.nq); e[a] = 1.0
+        return (L(qq, dd + e) - L(qq, dd - e)) / 2.0
+
+    scale = sum(sk.mass[:sk.n_links]) * 9.81
+    for a in range(sk.nq):
+        ddt = (dL_ddq(t0 + 1e-3, a) - dL_ddq(t0 - 1e-3, a)) / 2e-3
+        e = np.zeros(sk.nq); e[a] = 1e-6
+        ref = ddt - (L(q + e, dq) - L(q - e, dq)) / 2e-6
+        assert abs(E[a] - ref) < 2e-6 * scale, (a, E[a], ref)
+    # the first six rows are the ones the GRF fit uses (in units of M g)
+    E6, _ = oracle.grf_terms(sk, gopt, q, dq, ddq)
+    assert np.abs(E[:6] / scale - E6).max() < 1e-12
