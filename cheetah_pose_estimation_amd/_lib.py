@@ -71,6 +71,7 @@ def load():
     lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_eom_rows.argtypes = [vp, C.POINTER(abi.EomOptions), C.c_int32, C.c_int32, vp, vp, vp, vp]
+    lib.cpe_eom_residual.argtypes = [vp, C.POINTER(abi.DynOptions), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_grf_fit.argtypes = [vp, C.POINTER(abi.GrfOptions), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     _LIB = lib
     return lib
@@ -169,6 +170,11 @@ class Handle:
     def eom_rows(self, eopt, q, dq, ddq, rows):
         """all rows of d/dt dL/dq' - dL/dq (device tensors [B, N, nq])"""
         _check(self.lib.cpe_eom_rows(self._h, C.byref(eopt), q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(ddq), _ptr(rows)), "cpe_eom_rows")
+
+    def eom_residual(self, dopt, q, dq, ddq, tau, lam, grf, residual):
+        """rows of the equations of motion minus the generalised forces (device tensors; tau / lam / grf may be None)"""
+        _check(self.lib.cpe_eom_residual(self._h, C.byref(dopt), q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(ddq), _ptr(tau), _ptr(lam),
+                                         _ptr(grf), _ptr(residual)), "cpe_eom_residual")
 
     def grf_fit(self, gopt, q, dq, ddq, contact, grfz, grfxy, residual=None):
         """per-frame ground-reaction-force fit (device tensors); contact int32 [B, N, n_feet]"""

@@ -98,6 +98,12 @@ class EomOptions(C.Structure):
     _fields_ = [("gravity", C.c_double), ("link_inertia", d3 * MAX_LINKS)]
 
 
+class DynOptions(C.Structure):
+    """mirror of cpe_dyn_options (include/cpe.h)"""
+    _fields_ = [("eom", EomOptions), ("n_feet", C.c_int32), ("n_motors", C.c_int32), ("foot_marker", C.c_int32 * 4),
+                ("motor_first", C.c_int32 * 32), ("motor_second", C.c_int32 * 32), ("motor_axis", C.c_int32 * 32)]
+
+
 def default_options(fps: float = 120.0) -> Options:
     """Same defaults as cpe_default_options() in csrc/cpe_api.cpp."""
     o = Options()

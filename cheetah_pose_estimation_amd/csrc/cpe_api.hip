@@ -35,6 +35,7 @@ struct cpe_handle {
     int* flag = nullptr;
     int* act = nullptr;          // [ws_B] sequences of the current launch window
     cpe_eom_options* eom = nullptr;   // device copy of the last cpe_eom_rows options
+    cpe_dyn_options* dyn = nullptr;   // device copy of the last cpe_eom_residual options
     // learned priors (config 3)
     DevPriors* pri = nullptr;    // device copy, nullptr without priors
     int gmm_k = 0, gmm_dim = 0, lr_window = 0;
@@ -415,6 +416,7 @@ void cpe_destroy(cpe_handle* h) {
     if (h->flag) (void)hipFree(h->flag);
     if (h->pri) (void)hipFree(h->pri);
     if (h->eom) (void)hipFree(h->eom);
+    if (h->dyn) (void)hipFree(h->dyn);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -510,6 +512,27 @@ cpe_status cpe_eom_rows(cpe_handle* h, const cpe_eom_options* opt, int32_t B, in
     if (!h->eom) HIPCHK(hipMalloc(&h->eom, sizeof(cpe_eom_options)));
     HIPCHK(hipMemcpyAsync(h->eom, opt, sizeof(cpe_eom_options), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_eom, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->eom, F, q, dq, ddq, rows);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
+cpe_status cpe_eom_residual(cpe_handle* h, const cpe_dyn_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
+                            const double* ddq, const double* tau, const double* lambda, const double* grf, double* residual) {
+    if (!h || !opt || !q || !dq || !ddq || !residual) return fail(CPE_BAD_ARG, "null argument");
+    if (opt->n_feet < 0 || opt->n_feet > 4 || opt->n_motors < 0 || opt->n_motors > 32) return fail(CPE_BAD_ARG, "dynamics options out of range");
+    for (int f = 0; f < opt->n_feet; f++) if (opt->foot_marker[f] < 0 || opt->foot_marker[f] >= h->hm.L) return fail(CPE_BAD_ARG, "foot marker index out of range");
+    for (int m = 0; m < opt->n_motors; m++)
+        if (opt->motor_first[m] < 0 || opt->motor_first[m] >= h->hm.nl || opt->motor_second[m] < 0 || opt->motor_second[m] >= h->hm.nl ||
+            opt->motor_axis[m] < 0 || opt->motor_axis[m] > 2) return fail(CPE_BAD_ARG, "motor definition out of range");
+    cpe_status s = cpe_eom_rows(h, &opt->eom, B, N, q, dq, ddq, residual);
+    if (s != CPE_OK) return s;
+    const size_t F = (size_t)B * N;
+    if (F == 0 || (!tau && !lambda && !grf)) return CPE_OK;
+    if (!h->dyn) HIPCHK(hipMalloc(&h->dyn, sizeof(cpe_dyn_options)));
+    HIPCHK(hipMemcpyAsync(h->dyn, opt, sizeof(cpe_dyn_options), hipMemcpyHostToDevice, h->stream));
+    int n_con = 0;
+    for (int j = 0; j < h->hm.nj; j++) n_con += h->hm.joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
+    hipLaunchKernelGGL(k_dyn_forces, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, h->dyn, F, q, tau, lambda, grf, n_con, residual);
     HIPCHK(hipGetLastError());
     return CPE_OK;
 }

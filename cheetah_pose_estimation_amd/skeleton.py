@@ -259,3 +259,22 @@ def eom_options(animal: str = "phantom") -> abi.EomOptions:
         o.link_inertia[i][1] = perp
         o.link_inertia[i][2] = perp if along_x else ax
     return o
+
+
+# motors of the physics-based model: add_torque(first, second, about=...) in cheetah.py:70-165 -- 3 + 3 + 2 + 2 + 4 x 3 = 22 torques
+MOTORS = ([("bodyF", "base", a) for a in "xyz"] + [("neck", "bodyF", a) for a in "xyz"] +
+          [("base", "tail0", a) for a in "yz"] + [("tail0", "tail1", a) for a in "yz"] +
+          [m for leg, body in (("FL", "bodyF"), ("FR", "bodyF"), ("BL", "base"), ("BR", "base"))
+           for m in ((body, "U" + leg, "y"), ("U" + leg, "L" + leg, "y"), ("L" + leg, "H" + leg, "y"))])
+
+
+def dyn_options(animal: str = "phantom") -> abi.DynOptions:
+    o = abi.DynOptions()
+    o.eom = eom_options(animal)
+    o.n_feet = 4
+    for i, name in enumerate(FOOT_MARKERS):
+        o.foot_marker[i] = MARKERS.index(name)
+    o.n_motors = len(MOTORS)
+    for i, (a, b, ax) in enumerate(MOTORS):
+        o.motor_first[i], o.motor_second[i], o.motor_axis[i] = LINKS.index(a), LINKS.index(b), "xyz".index(ax)
+    return o

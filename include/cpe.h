@@ -239,6 +239,25 @@ typedef struct cpe_eom_options {
 cpe_status cpe_eom_rows(cpe_handle* h, const cpe_eom_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
                         const double* ddq, double* rows);
 
+/* ---- generalised forces of the physics-based model: what the rows above are balanced against,
+ *   Q = B_grf + B_tau + (dc/dq)^T lambda,
+ *   B_grf = sum_feet (d foot / dq)^T  M g (GRFz e_z + sum_k D_k GRFxy_k),  D = [+x, +y, -x, -y]   (forces in body weights)
+ *   B_tau = sum_motors (J_w,second - J_w,first)^T  M g tau  R_first e_axis,  J_w,i = d w_i(world) / dq' = R_i dw_i(body)/dq'
+ *   c     = the joint equalities in the order of cpe_skeleton.joint_* (two rows per revolute, one per hooke joint)
+ * cpe_eom_residual returns rows - Q (the reference's slack_eom).  The pairing of the reference's motor names with
+ * (first, second, axis) follows cheetah.py:70-165 and is supplied by the caller; against the reference's `.robot` pickles
+ * this is "parity unpinned" -- the tests check virtual work instead (Q . q' = sum F . v_foot + sum T . (w_second - w_first)). */
+typedef struct cpe_dyn_options {
+    cpe_eom_options eom;
+    int32_t n_feet, n_motors;
+    int32_t foot_marker[4];
+    int32_t motor_first[32], motor_second[32], motor_axis[32];      /* axis 0/1/2 = x/y/z of the FIRST link */
+} cpe_dyn_options;
+/* tau [B][N][n_motors], lambda [B][N][n_constraints], grf [B][N][n_feet][5] = (z, +x, +y, -x, -y) per foot; any may be NULL (= 0).
+ * residual [B][N][nq].  Device pointers. */
+cpe_status cpe_eom_residual(cpe_handle* h, const cpe_dyn_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
+                            const double* ddq, const double* tau, const double* lambda, const double* grf, double* residual);
+
 /* forward kinematics only (get_pose_state / get_com, acinoset_misc.py:1581-1659, :722-742); device ptrs */
 cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q,
                                   double* positions /*[B][N][L][3]*/, double* com /*[B][N][3] or NULL*/);

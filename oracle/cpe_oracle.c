@@ -1070,6 +1070,57 @@ void cpo_eom_rows(const cpe_skeleton* s, const cpe_eom_options* o, const double*
     }
 }
 
+/* generalised forces Q[nq] of the physics-based model (include/cpe.h, cpe_eom_residual); tau / lam / grf may be NULL */
+void cpo_dyn_forces(const cpe_skeleton* s, const cpe_dyn_options* o, const double* q, const double* tau, const double* lam,
+                    const double* grf, double* Q) {
+    int nl = s->n_links, nq = NQ(s);
+    double R[CPE_MAX_LINKS * 9], dR[CPE_MAX_LINKS][3][9], M = 0, g = o->eom.gravity;
+    for (int i = 0; i < nl; i++) { cpo_rot(q + 3 + 3 * i, R + 9 * i); cpo_drot(q + 3 + 3 * i, dR[i]); M += s->mass[i]; }
+    for (int p = 0; p < nq; p++) Q[p] = 0;
+    static const double D[5][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, -1, 0}};
+    if (grf)
+        for (int f = 0; f < o->n_feet; f++) {
+            double F[3] = {0, 0, 0};
+            for (int k = 0; k < 5; k++) for (int d = 0; d < 3; d++) F[d] += M * g * grf[5 * f + k] * D[k][d];
+            for (int d = 0; d < 3; d++) Q[d] += F[d];
+            /* chain of the foot marker: marker link, then up through the parents; vector on each link */
+            int l = o->foot_marker[f], k = s->marker_link[l];
+            const double* v = s->marker_off[l];
+            while (k >= 0) {
+                for (int a = 0; a < 3; a++) { double t[3]; matvec3(dR[k][a], v, t); Q[3 + 3 * k + a] += F[0] * t[0] + F[1] * t[1] + F[2] * t[2]; }
+                v = s->attach[k]; k = s->parent[k];
+            }
+        }
+    if (tau)
+        for (int m = 0; m < o->n_motors; m++) {
+            int a1 = o->motor_first[m], a2 = o->motor_second[m], ax = o->motor_axis[m];
+            double T[3];
+            for (int d = 0; d < 3; d++) T[d] = M * g * tau[m] * R[9 * a1 + 3 * d + ax];
+            for (int side = 0; side < 2; side++) {
+                int i = side == 0 ? a2 : a1; double sg = side == 0 ? 1.0 : -1.0;
+                double w[3], al[3], Jw[3][3], zero[3] = {0, 0, 0};
+                body_rates(q + 3 + 3 * i, zero, zero, w, al, Jw);
+                for (int a = 0; a < 3; a++) {
+                    double col[3] = {Jw[0][a], Jw[1][a], Jw[2][a]}, wc[3];
+                    matvec3(R + 9 * i, col, wc);                                   /* d w_world / d q'_a */
+                    Q[3 + 3 * i + a] += sg * (T[0] * wc[0] + T[1] * wc[1] + T[2] * wc[2]);
+                }
+            }
+        }
+    if (lam) {
+        double c[64], Cq[64 * CPE_MAX_NQ];
+        int nc = cpo_constraints(s, q, c, Cq);
+        for (int r = 0; r < nc; r++) for (int p = 0; p < nq; p++) Q[p] += Cq[r * nq + p] * lam[r];
+    }
+}
+void cpo_eom_residual(const cpe_skeleton* s, const cpe_dyn_options* o, const double* q, const double* dq, const double* ddq,
+                      const double* tau, const double* lam, const double* grf, double* res) {
+    double Q[CPE_MAX_NQ];
+    cpo_eom_rows(s, &o->eom, q, dq, ddq, res);
+    cpo_dyn_forces(s, o, q, tau, lam, grf, Q);
+    for (int p = 0; p < NQ(s); p++) res[p] -= Q[p];
+}
+
 /* projection of y0[5] = (z, x0..x3) onto {0 <= . <= fmax, sum x <= mu z}: clamp(y0 - lam n), n = (-mu, 1, 1, 1, 1), lam >= 0 by bisection */
 static void grf_project(double* y, double mu, double fmax) {
     double y0[5]; memcpy(y0, y, sizeof(y0));

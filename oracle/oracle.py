@@ -217,3 +217,17 @@ def eom_rows(sk, eopt, q, dq, ddq):
     E = np.empty(sk.nq)
     lib().cpo_eom_rows(C.byref(sk), C.byref(eopt), _p(_c(q)), _p(_c(dq)), _p(_c(ddq)), _p(E))
     return E
+
+
+def dyn_forces(sk, dopt, q, tau=None, lam=None, grf=None):
+    Q = np.empty(sk.nq)
+    lib().cpo_dyn_forces(C.byref(sk), C.byref(dopt), _p(_c(q)), _p(_c(tau)) if tau is not None else None,
+                         _p(_c(lam)) if lam is not None else None, _p(_c(grf)) if grf is not None else None, _p(Q))
+    return Q
+
+
+def eom_residual(sk, dopt, q, dq, ddq, tau=None, lam=None, grf=None):
+    r = np.empty(sk.nq)
+    lib().cpo_eom_residual(C.byref(sk), C.byref(dopt), _p(_c(q)), _p(_c(dq)), _p(_c(ddq)), _p(_c(tau)) if tau is not None else None,
+                           _p(_c(lam)) if lam is not None else None, _p(_c(grf)) if grf is not None else None, _p(r))
+    return r

@@ -513,3 +513,31 @@ def test_eom_rows_match_oracle(oracle, gpu_handle_factory):
         for n in range(16):
             E = oracle.eom_rows(sk, eopt, q[b, n], dq[b, n], ddq[b, n])
             assert np.abs(rows[b, n] - E).max() < 1e-10 * scale
+
+
+def test_eom_residual_with_forces_matches_oracle(oracle, gpu_handle_factory):
+    """rows of the equations of motion minus foot forces, motor torques and joint constraint forces, HIP vs oracle"""
+    import torch
+    sk = skeleton.build_skeleton("phantom", 24)
+    dopt = skeleton.dyn_options("phantom")
+    h = gpu_handle_factory(sk, synth.make_cameras(1))
+    d = synth.make_batch(sk, synth.make_cameras(1), B=2, N=8, seed=31)
+    q = d["q_true"]
+    dq = np.zeros_like(q); ddq = np.zeros_like(q)
+    for b in range(2):
+        dq[b], ddq[b] = oracle.derivatives(q[b], 1.0 / 120.0)
+    rng = np.random.default_rng(2)
+    tau = rng.normal(0, 0.5, (2, 8, 22)); lam = rng.normal(0, 0.5, (2, 8, 26)); grf = rng.uniform(0, 2, (2, 8, 4, 5))
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    res = torch.empty((2, 8, sk.nq), dtype=torch.float64, device=dev)
+    scale = sum(sk.mass[:sk.n_links]) * 9.81
+    for use in ((True, True, True), (False, False, True), (True, False, False), (False, True, False), (False, False, False)):
+        h.eom_residual(dopt, T(q), T(dq), T(ddq), T(tau) if use[0] else None, T(lam) if use[1] else None, T(grf) if use[2] else None, res)
+        h.synchronize()
+        got = res.cpu().numpy()
+        for b in range(2):
+            for n in range(8):
+                ref = oracle.eom_residual(sk, dopt, q[b, n], dq[b, n], ddq[b, n], tau[b, n] if use[0] else None,
+                                          lam[b, n] if use[1] else None, grf[b, n] if use[2] else None)
+                assert np.abs(got[b, n] - ref).max() < 1e-10 * scale

@@ -149,3 +149,49 @@ def test_all_eom_rows_match_a_numerical_lagrangian(oracle):
     # the first six rows are the ones the GRF fit uses (in units of M g)
     E6, _ = oracle.grf_terms(sk, gopt, q, dq, ddq)
     assert np.abs(E[:6] / scale - E6).max() < 1e-12
+
+
+def test_generalised_forces_do_the_right_virtual_work(oracle):
+    """cpo_dyn_forces: for any q' the power of the generalised forces equals the power of the physical ones --
+    foot forces times foot velocities, motor torques times the relative angular velocity of the two links about the motor's
+    axis, and constraint forces through d c / dt."""
+    sk = skeleton.build_skeleton("phantom", 24)
+    dopt = skeleton.dyn_options("phantom")
+    assert dopt.n_motors == 22
+    rng = np.random.default_rng(11)
+    q = _traj(sk, 0.4)
+    Mg = sum(sk.mass[:sk.n_links]) * dopt.eom.gravity
+    D = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, -1, 0.0]])
+    h = 1e-6
+    for _ in range(3):
+        dq = rng.normal(0, 1, sk.nq)
+        # feet
+        grf = rng.uniform(0, 2, (4, 5))
+        Q = oracle.dyn_forces(sk, dopt, q, grf=grf)
+        vel = (oracle.markers(sk, q + h * dq) - oracle.markers(sk, q - h * dq)) / (2 * h)
+        power = sum(Mg * (grf[f] @ D) @ vel[dopt.foot_marker[f]] for f in range(4))
+        assert abs(Q @ dq - power) < 1e-6 * max(1.0, abs(power))
+        # motors: T . (w_second - w_first) with w from the rotation matrices, w_world = vee(R' R^T)
+        tau = rng.normal(0, 1, 22)
+        Q = oracle.dyn_forces(sk, dopt, q, tau=tau)
+        Rm = lambda qq: synth.rot_zyx(qq[3:].reshape(sk.n_links, 3))
+        Rd = (Rm(q + h * dq) - Rm(q - h * dq)) / (2 * h)
+        W = np.einsum("lij,lkj->lik", Rd, Rm(q))                                   # R' R^T = [w]_x
+        w = np.stack([W[:, 2, 1], W[:, 0, 2], W[:, 1, 0]], axis=1)
+        power = 0.0
+        for m in range(22):
+            a1, a2, ax = dopt.motor_first[m], dopt.motor_second[m], dopt.motor_axis[m]
+            power += Mg * tau[m] * Rm(q)[a1][:, ax] @ (w[a2] - w[a1])
+        assert abs(Q @ dq - power) < 1e-6 * max(1.0, abs(power))
+        # constraint forces: lambda . dc/dt
+        lam = rng.normal(0, 1, 26)
+        Q = oracle.dyn_forces(sk, dopt, q, lam=lam)
+        cdot = (np.array(oracle.constraints(sk, q + h * dq)) - np.array(oracle.constraints(sk, q - h * dq))) / (2 * h)
+        assert abs(Q @ dq - lam @ cdot) < 1e-6 * max(1.0, abs(lam @ cdot))
+    # residual = rows - Q, linear in the forces
+    dq = rng.normal(0, 1, sk.nq); ddq = rng.normal(0, 5, sk.nq)
+    r0 = oracle.eom_residual(sk, dopt, q, dq, ddq)
+    assert np.abs(r0 - oracle.eom_rows(sk, dopt.eom, q, dq, ddq)).max() == 0
+    r1 = oracle.eom_residual(sk, dopt, q, dq, ddq, tau=tau, lam=lam, grf=grf)
+    Qs = oracle.dyn_forces(sk, dopt, q, tau=tau) + oracle.dyn_forces(sk, dopt, q, lam=lam) + oracle.dyn_forces(sk, dopt, q, grf=grf)
+    assert np.abs(r1 - (r0 - Qs)).max() < 1e-9 * Mg
