@@ -541,3 +541,43 @@ def test_eom_residual_with_forces_matches_oracle(oracle, gpu_handle_factory):
                 ref = oracle.eom_residual(sk, dopt, q[b, n], dq[b, n], ddq[b, n], tau[b, n] if use[0] else None,
                                           lam[b, n] if use[1] else None, grf[b, n] if use[2] else None)
                 assert np.abs(got[b, n] - ref).max() < 1e-10 * scale
+
+
+def test_full_size_properties(sk25, cams6, gpu_handle_factory):
+    """BASELINE.json's size (2 048 sequences x 200 frames x 6 cameras x 25 markers, 13.7 GB per launch) through properties that
+    need no oracle: copies of one sequence give bit-identical rows wherever they land in the grid (persistent workgroups, grid
+    stride); residual + measurement does not depend on the measurement; J and eps do not depend on it at all; eps vanishes on
+    the first three frames of every sequence; and a full-size solve converges everywhere with the joint equalities at round-off."""
+    import torch
+    h = gpu_handle_factory(sk25, cams6)
+    B, N, P = 2048, 200, 16
+    d = synth.make_batch(sk25, cams6, B=P, N=N, seed=77)
+    dev = torch.device("cuda", 0)
+    rep = B // P
+    T = {k: torch.tensor(d[k], device=dev).repeat((rep,) + (1,) * (d[k].ndim - 1)).contiguous() for k in ("q_true", "q_init", "meas", "weight")}
+    S = h.S
+    r = torch.empty((B, N, 6, 25, 2), dtype=torch.float64, device=dev); J = torch.empty((B, N, 6, S, 2), dtype=torch.float64, device=dev)
+    eps = torch.empty((B, N, sk25.nq), dtype=torch.float64, device=dev)
+    h.eval_resjac(T["q_true"], T["meas"], T["weight"], r, J, eps, None); h.synchronize()
+    for k in (1, rep // 2, rep - 1):                                            # copies far apart in the grid
+        assert torch.equal(r[:P], r[k * P:(k + 1) * P]) and torch.equal(J[:P], J[k * P:(k + 1) * P]) and torch.equal(eps[:P], eps[k * P:(k + 1) * P])
+    assert float(eps[:, :3].abs().max()) == 0.0 and float(eps[:, 3:].abs().max()) > 0.0
+    uv = r[:P] + T["meas"][:P]
+    Jsum, esum = float(J.sum()), float(eps.sum())
+    meas2 = T["meas"] + 7.25
+    h.eval_resjac(T["q_true"], meas2, T["weight"], r, J, eps, None); h.synchronize()
+    assert float((r[:P] + meas2[:P] - uv).abs().max()) < 1e-9                   # same projection
+    assert float(J.sum()) == Jsum and float(eps.sum()) == esum
+    del r, J, eps, meas2
+    torch.cuda.empty_cache()
+    Bs = 512
+    q = torch.empty((Bs, N, sk25.nq), dtype=torch.float64, device=dev); dq = torch.empty_like(q); ddq = torch.empty_like(q)
+    pos = torch.empty((Bs, N, 25, 3), dtype=torch.float64, device=dev); me = torch.empty((Bs, N, 6, 25, 2), dtype=torch.float64, device=dev)
+    st, stats = h.solve(T["q_init"][:Bs], T["meas"][:Bs], T["weight"][:Bs], q, dq, ddq, pos, me)
+    assert st == abi.OK and all(s.status == abi.OK for s in stats)
+    its = np.array([s.iterations for s in stats]).reshape(Bs // P, P)
+    assert (its == its[0]).all()                                                # copies take the same number of iterations
+    assert max(s.max_constraint for s in stats) < 1e-12
+    assert float((q[:P] - q[Bs - P:]).abs().max()) < 1e-9                       # and land on the same trajectory (LDS atomics reorder sums)
+    err = float(((pos[:P] - torch.tensor(synth.fk_numpy(sk25, d["q_true"])[0], device=dev)) ** 2).sum(-1).mean().sqrt())
+    assert err < 0.02                                                           # 2 px noise, 10 % outliers: centimetre level
