@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
+    ap.add_argument("--no-l24", action="store_true", help="skip the extra 24-marker residual+Jacobian measurement")
     args = ap.parse_args()
 
     import torch
@@ -146,11 +147,38 @@ def main():
     frames_total = world * B * N * args.steps
     value = frames_total / elapsed
 
+    # "also report L=24" -- the reference's own 24 markers, same cameras and sequence shape, same kernel
+    l24 = None
+    if L == 25 and world == 1 and not args.no_l24:
+        del r, J, eps
+        sk24 = skeleton.build_skeleton("phantom", 24)
+        h24 = _lib.Handle(sk24, cams, opts, device=local)
+        d24 = synth.make_batch(sk24, cams, B=P, N=N, seed=1234)
+        t24 = tile_batch(torch, d24, B, dev, seed=7)
+        r = torch.empty((B, N, C, 24, 2), dtype=torch.float64, device=dev)
+        J = torch.empty((B, N, C, h24.S, 2), dtype=torch.float64, device=dev)
+        eps = torch.empty((B, N, sk24.nq), dtype=torch.float64, device=dev)
+        s24 = torch.cuda.ExternalStream(h24.stream, device=dev)
+        for _ in range(2):
+            h24.eval_resjac(t24["q_true"], t24["meas"], t24["weight"], r, J, eps, None)
+        h24.synchronize()
+        e24 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in e24:
+            a.record(s24)
+            h24.eval_resjac(t24["q_true"], t24["meas"], t24["weight"], r, J, eps, None)
+            b.record(s24)
+        h24.synchronize()
+        ms24 = float(np.mean([a.elapsed_time(b) for a, b in e24]))
+        l24 = dict(value=B * N / (ms24 * 1e-3), unit="frames/s", kernel_ms=ms24, bytes_per_frame=BYTES_PER_FRAME[24],
+                   frac=BYTES_PER_FRAME[24] * B * N / (ms24 * 1e-3) / HBM_PEAK)
+        h24.close()
+        del t24
+
     solves = None
     if not args.no_solve:
         Bs = args.solve_batch
         ts_ = tile_batch(torch, d, Bs, dev, seed=100 + rank)
-        del r, J, eps
+        r = J = eps = None
         q = torch.empty((Bs, N, sk.nq), dtype=torch.float64, device=dev); dq = torch.empty_like(q); ddq = torch.empty_like(q)
         pos = torch.empty((Bs, N, L, 3), dtype=torch.float64, device=dev); me = torch.empty((Bs, N, C, L, 2), dtype=torch.float64, device=dev)
         h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)   # warm-up at full size: the solver workspace (16 GB for 2048 sequences) is allocated here
@@ -178,7 +206,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2: synthetic 200-frame x 6-cam x 25-marker sequences, phantom skeleton, const-accel model",
                        "frames": N, "cams": C, "markers": L, "sequences_per_gpu": B, "parallelism": f"shard{world} (independent sequences, no collective)"},
-            "solves": solves,
+            "solves": solves, "markers24": l24,
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                          "traffic": pmc_traffic(B, N, C, L), "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
         }

@@ -67,6 +67,8 @@ def load():
     lib.cpe_eval_resjac_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_project_joints.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.cpe_forward_kinematics.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.cpe_marker_velocities.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+    lib.cpe_reproject.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     lib.cpe_eval_normal.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
@@ -154,6 +156,38 @@ class Handle:
     def forward_kinematics(self, q, positions, com=None):
         _check(self.lib.cpe_forward_kinematics(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(positions), _ptr(com)),
                "cpe_forward_kinematics")
+
+    def marker_velocities(self, q, dq, velocities):
+        """v_l = (d p_l / d q) dq for every marker (device tensors; velocities [B, N, L, 3])"""
+        _check(self.lib.cpe_marker_velocities(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(velocities)),
+               "cpe_marker_velocities")
+
+    def reproject(self, positions, uv):
+        """stored 3D markers -> pixels in every camera (device tensors; uv [B, N, C, L, 2])"""
+        _check(self.lib.cpe_reproject(self._h, positions.shape[0], positions.shape[1], _ptr(positions), _ptr(uv)), "cpe_reproject")
+
+    def reproject_host(self, positions):
+        """numpy [B, N, L, 3] -> numpy [B, N, C, L, 2] (staged through HBM with torch)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        pd = torch.tensor(np.ascontiguousarray(positions, dtype=np.float64), device=dev)
+        uv = torch.empty((pd.shape[0], pd.shape[1], self.n_cams, self.L, 2), dtype=torch.float64, device=dev)
+        self.reproject(pd, uv)
+        self.synchronize()
+        return uv.cpu().numpy()
+
+    def kinematics_host(self, q, dq):
+        """numpy in, numpy out (staged through HBM with torch): positions [B, N, L, 3], marker velocities [B, N, L, 3]"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        qd = torch.tensor(np.ascontiguousarray(q, dtype=np.float64), device=dev)
+        dqd = torch.tensor(np.ascontiguousarray(dq, dtype=np.float64), device=dev)
+        B, N = qd.shape[0], qd.shape[1]
+        pos = torch.empty((B, N, self.L, 3), dtype=torch.float64, device=dev); vel = torch.empty_like(pos)
+        self.forward_kinematics(qd, pos, None)
+        self.marker_velocities(qd, dqd, vel)
+        self.synchronize()
+        return pos.cpu().numpy(), vel.cpu().numpy()
 
     def eval_normal(self, q, meas, weight, g, Bm, cost, gam=None, q_out=None):
         _check(self.lib.cpe_eval_normal(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(meas), _ptr(weight), _ptr(g), _ptr(Bm), _ptr(cost),

@@ -547,6 +547,31 @@ cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const dou
     return CPE_OK;
 }
 
+cpe_status cpe_marker_velocities(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* dq, double* velocities) {
+    if (!h || !q || !dq || !velocities) return fail(CPE_BAD_ARG, "null argument");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t lds = sizeof(double) * (2 * h->hm.nq + 6 * h->hm.nl + 36 * h->hm.nl);
+    hipLaunchKernelGGL(k_marker_vel, dim3((unsigned)F), dim3(WAVE), lds, h->stream, h->dm, q, dq, velocities);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
+cpe_status cpe_reproject(cpe_handle* h, int32_t B, int32_t N, const double* positions, double* uv) {
+    if (!h || !positions || !uv) return fail(CPE_BAD_ARG, "null argument");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_reproject, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, positions, uv);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
 static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     const size_t F = (size_t)B * N;
     if (F <= h->ws_frames && B <= h->ws_B) return CPE_OK;

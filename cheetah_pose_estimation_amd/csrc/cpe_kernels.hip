@@ -371,6 +371,55 @@ __global__ __launch_bounds__(WAVE) void k_fk(const DevModel* __restrict__ M, con
 }
 
 // --------------------------------------------------------------------------------------------------
+// marker velocities v_l = (d p_l / d q) dq, the analytic foot velocity of the contact heuristic
+// (`foot.Pb_I_vel` lambdified in acinoset_misc.py:347-360).  One lane per marker walks the marker's Jacobian slots.
+// dynamic LDS: q[nq] | dq[nq] | sc[6 nl] | R[36 nl]
+__global__ __launch_bounds__(WAVE) void k_marker_vel(const DevModel* __restrict__ M, const double* __restrict__ q,
+                                                     const double* __restrict__ dq, double* __restrict__ vel) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int nq = M->nq, nl = M->nl, L = M->L;
+    double* sq = smem;
+    double* sdq = sq + nq;
+    double* ssc = sdq + nq;
+    double* sR = ssc + 6 * nl;
+    const size_t f = blockIdx.x;
+    if (lane < nq) { sq[lane] = q[f * nq + lane]; sdq[lane] = dq[f * nq + lane]; }
+    wave_lds_sync();
+    wave_sincos(M, sq, ssc, lane);
+    wave_lds_sync();
+    wave_rotations(M, ssc, sR, lane);
+    wave_lds_sync();
+    if (lane < L) {
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        for (int s = M->slot_off[lane]; s < M->slot_off[lane + 1]; s++) {
+            double d0, d1, d2;
+            slot_dp(M, sR, s, d0, d1, d2);
+            const double w = sdq[M->slot_dof[s]];
+            v0 += d0 * w; v1 += d1 * w; v2 += d2 * w;
+        }
+        double* o = vel + (f * (size_t)L + lane) * 3;
+        o[0] = v0; o[1] = v1; o[2] = v2;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// reprojection of stored 3D marker positions into every camera, for the cam*_fte writers
+// (acinoset_misc.py:1339-1407).  One lane per (camera, marker) pair; no LDS.
+__global__ __launch_bounds__(WAVE) void k_reproject(const DevModel* __restrict__ M, const double* __restrict__ positions,
+                                                    double* __restrict__ uv) {
+    const int L = M->L, CL = M->C * L;
+    const size_t f = blockIdx.x;
+    const double* P = positions + f * (size_t)(3 * L);
+    for (int t = threadIdx.x; t < CL; t += WAVE) {
+        const int c = t / L, l = t - c * L;
+        double u, v, G[6];
+        project_point(M->cam[c], P[3 * l], P[3 * l + 1], P[3 * l + 2], u, v, G);
+        reinterpret_cast<double2*>(uv)[f * (size_t)CL + t] = make_double2(u, v);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // dependent-angle projection in place.  dynamic LDS: q[nq] | sc[6 nl]
 __global__ __launch_bounds__(WAVE) void k_project(const DevModel* __restrict__ M, double* __restrict__ q,
                                                   int* __restrict__ clamped_flag) {

@@ -330,10 +330,14 @@ class CheetahEstimator:
                 off[o["cam"]] = o["frame"]
         all_cams = scene_cameras(Scene(scene.scene_fpath, scene.k_arr, scene.d_arr, scene.r_arr, scene.t_arr, scene.cam_res,
                                        scene.fps, scene.n_cams, None), params.kinetic_dataset)
-        from .synth import project_numpy
         pos = res["positions"][0]
+        hw = _lib.Handle(self.skeleton, all_cams, device=self.device)          # every camera of the scene, also for monocular runs
+        try:
+            uv_all = hw.reproject_host(pos[None])[0]                           # [N, C, 24, 2] on the GPU (cpe_reproject)
+        finally:
+            hw.close()
         for i in range(scene.n_cams):
-            uv, _ = project_numpy(all_cams[i], pos)
+            uv = uv_all[:, i].copy()
             bad = (uv > np.array(scene.cam_res)) | (uv < 0)
             uv[bad.any(-1)] = np.nan                                # acinoset_misc.py:1385-1386
             n_frames = pos.shape[0]
@@ -452,8 +456,43 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
     return ok
 
 
-def determine_contacts(estimator, monocular: bool = False, verbose: bool = False):
-    raise NotImplementedError("contact detection (acinoset_opt.py:638-690) is a CPU pre-step outside the hot path (SURVEY 8f-2)")
+def determine_contacts(estimator: CheetahEstimator, monocular: bool = False, verbose: bool = True,
+                       out_dir_prefix: Optional[str] = None):
+    """Contact windows from the kinematic reconstruction + template forces, acinoset_opt.py:636-692: reads
+    `fte_kinematic[_<cam>]/fte.pickle` (written by `CheetahEstimator.save`), evaluates foot heights and analytic foot
+    velocities on the GPU (cpe_forward_kinematics, cpe_marker_velocities), applies the height / zero-velocity / stance-time
+    heuristic (contacts.contact_detection) and writes `grf/autogen-contact.json`, `grf/autogen-contact-02.json` and the two
+    synthetic force tables.  Returns (contacts, contacts_height_only) -- the reference prints them and returns None."""
+    from . import contacts as ct
+    params, scene, sk = estimator.params, estimator.scene, estimator.skeleton
+    data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, estimator.data_path)
+    sub = "fte_kinematic" if not monocular else f"fte_kinematic_{scene.cam_idx}"
+    with open(os.path.join(data_dir, sub, "fte.pickle"), "rb") as fh:              # written by CheetahEstimator.save
+        fte = pickle.load(fh)
+    estimator.com_vel, estimator.com_pos = fte["com_vel"], fte["com_pos"]
+    h = _lib.Handle(sk, estimator.cams, device=estimator.device)
+    try:
+        pos, vel = h.kinematics_host(fte["q"][None], fte["dq"][None])
+    finally:
+        h.close()
+    feet_idx = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    names = [f"{f}_foot" for f in skeleton.FEET]
+    speed = float(np.mean(np.linalg.norm(estimator.com_vel, axis=1)))
+    contacts, by_height = ct.contact_detection(pos[0][:, feet_idx, 2], vel[0][:, feet_idx, 2], names, params.start_frame, speed, scene.fps)
+    if verbose:
+        print("Height, velocity, stance time heuristic:")
+        print(contacts)
+        print("Height:")
+        print(by_height)
+    grf_dir = os.path.join(data_dir, "grf")
+    n_frames = pos.shape[1]
+    ct.write_contacts(grf_dir, params.start_frame, n_frames, contacts, by_height)
+    direction = 1.0 if float(np.mean(estimator.com_vel, axis=0)[0]) < 0 else -1.0
+    for cname, oname in (("autogen-contact.json", "data_synth"), ("autogen-contact-02.json", "data_synth_02")):
+        with open(os.path.join(grf_dir, cname), "r", encoding="utf-8") as fh:
+            cj = json.load(fh)
+        ct.write_synth_grf(os.path.join(grf_dir, f"{oname}.csv"), ct.synth_grf(cj, names, speed, direction))
+    return contacts, by_height
 
 
 def estimate_kinetics(estimator, *args, **kwargs) -> bool:

@@ -262,6 +262,16 @@ cpe_status cpe_eom_residual(cpe_handle* h, const cpe_dyn_options* opt, int32_t B
 cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q,
                                   double* positions /*[B][N][L][3]*/, double* com /*[B][N][3] or NULL*/);
 
+/* marker velocities v_l = (d p_l / d q) dq (the lambdified `foot.Pb_I_vel` of the contact heuristic, acinoset_misc.py:347-360,
+ * for every marker); device ptrs */
+cpe_status cpe_marker_velocities(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* dq,
+                                 double* velocities /*[B][N][L][3]*/);
+
+/* reprojection of 3D marker positions into every camera of the handle, for the cam*_fte.{h5,csv} writers
+ * (acinoset_misc.py:1339-1407: cv.fisheye.projectPoints / pt3d_to_2d per camera); device ptrs */
+cpe_status cpe_reproject(cpe_handle* h, int32_t B, int32_t N, const double* positions /*[B][N][L][3]*/,
+                         double* uv /*[B][N][C][L][2]*/);
+
 #ifdef __cplusplus
 }
 #endif
