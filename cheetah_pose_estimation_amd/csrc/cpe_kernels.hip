@@ -160,7 +160,7 @@ __global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevM
         const int l = M->slot_marker[s], cpos = M->slot_cpos[s];
         sli[S + s] = l;
         if (cpos < 0) {
-            const int ax = M->slot_dof[s];
+            const int ax = cpos == -2 ? 3 : M->slot_dof[s];            // -2: alignment slot, structurally zero
             slv[s] = ax == 0 ? 1.0 : 0.0; slv[S + s] = ax == 1 ? 1.0 : 0.0; slv[2 * S + s] = ax == 2 ? 1.0 : 0.0; sli[s] = -1;
         } else {
             slv[s] = M->chain_vec[l][cpos][0]; slv[S + s] = M->chain_vec[l][cpos][1]; slv[2 * S + s] = M->chain_vec[l][cpos][2];

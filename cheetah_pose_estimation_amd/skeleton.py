@@ -208,7 +208,7 @@ def independent_dofs(sk: abi.Skeleton) -> np.ndarray:
 
 def jacobian_layout(sk: abi.Skeleton):
     """(slot_marker, slot_dof): the structurally non-zero (marker, dof) pairs, marker-major; within a
-    marker: x, y, z, then the 3 angles of each link on the path root -> marker link."""
+    marker: x, y, z, then the 3 angles of each link on the path root -> marker link; then 0-3 zero alignment slots."""
     sm, sd = [], []
     for l in range(sk.n_markers):
         chain = []
@@ -220,6 +220,16 @@ def jacobian_layout(sk: abi.Skeleton):
         dofs = [0, 1, 2] + [3 + 3 * k + a for k in chain for a in range(3)]
         sm += [l] * len(dofs)
         sd += dofs
+        if l == 0:
+            chain0 = list(chain)
+    # alignment slots (cpe_api.hip build_model): the count is padded to a multiple of 4 with structurally zero pairs of
+    # marker 0 -- dofs outside its chain, highest first -- so that a camera row of J is a whole number of 64-byte lines
+    d = sk.n_links * 3 + 2
+    while len(sm) % 4 and d >= 3:
+        if (d - 3) // 3 not in chain0:
+            sm.append(0)
+            sd.append(d)
+        d -= 1
     return np.array(sm, dtype=np.int32), np.array(sd, dtype=np.int32)
 
 

@@ -151,7 +151,9 @@ void cpe_default_options(cpe_options* o);
 void* cpe_stream(cpe_handle* h);
 cpe_status cpe_synchronize(cpe_handle* h);
 
-/* number of structurally non-zero (marker, dof) Jacobian slots: sum_l (3 + 3*chain_len(l)) */
+/* number of Jacobian slots: the structurally non-zero (marker, dof) pairs, sum_l (3 + 3*chain_len(l)), followed by 0-3
+ * structurally ZERO pairs (marker 0, a dof outside its chain; the stored value is 0) that round the count up to a multiple of 4,
+ * so that every camera row of J starts on a 64-byte line */
 int32_t cpe_jacobian_slots(const cpe_handle* h);
 /* slot -> (marker, dof) tables; caller provides int32[cpe_jacobian_slots] each */
 cpe_status cpe_jacobian_layout(const cpe_handle* h, int32_t* slot_marker, int32_t* slot_dof);
