@@ -392,6 +392,36 @@ void cpo_eval_resjac(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     free(pos); free(dpos);
 }
 
+/* bench.py's all-cores CPU baseline: `reps` passes of cpo_eval_resjac over B sequences, sequences spread over OpenMP
+ * threads, each thread writing into its own output buffers (what is timed is the evaluation, not one shared result
+ * array).  Returns the number of threads used.  Test infrastructure like everything in this file. */
+#include <omp.h>
+int cpo_eval_resjac_batch(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, int B, int N,
+                          const double* q, const double* meas, const double* weight, int reps, int threads, double* checksum) {
+    int nq = NQ(s), L = s->n_markers, used = 1;
+    double total = 0;
+    if (threads < 1) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads) reduction(+ : total)
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+        size_t nr = (size_t)N * C * L * 2;
+        double* r = (double*)malloc(sizeof(double) * nr);
+        double* J = (double*)malloc(sizeof(double) * nr * nq);
+        double* eps = (double*)malloc(sizeof(double) * (size_t)N * nq);
+        double* cost = (double*)malloc(sizeof(double) * N);
+#pragma omp for schedule(dynamic, 1)
+        for (int k = 0; k < B * reps; k++) {
+            int b = k % B;
+            cpo_eval_resjac(s, cams, C, o, N, q + (size_t)b * N * nq, meas + (size_t)b * nr, weight + (size_t)b * N * C * L, r, J, eps, cost);
+            for (int n = 0; n < N; n++) total += cost[n];
+        }
+        free(r); free(J); free(eps); free(cost);
+    }
+    if (checksum) *checksum = total;
+    return used;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* relative angles x (acinoset_misc.py:508-528 numpy branch + mask :1699-1757), linear in q */
 void cpo_relative_angles(const cpe_skeleton* s, const double* q, double* x /*[nu]*/) {

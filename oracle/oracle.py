@@ -75,6 +75,16 @@ def com(sk, q):
     return out.reshape(shp + (3,))
 
 
+def eval_resjac_batch(sk, cams, opts, q, meas, weight, reps=1, threads=1):
+    """bench.py's CPU leg: `reps` passes over q[B,N,nq] ... on `threads` OpenMP threads (0 = all), output buffers reused per
+    thread; returns (threads used, sum of the robust costs)"""
+    q, meas, weight = _c(q), _c(meas), _c(weight)
+    B, N, Cn, L = weight.shape
+    chk = C.c_double(0.0)
+    used = lib().cpo_eval_resjac_batch(C.byref(sk), cams, Cn, C.byref(opts), B, N, _p(q), _p(meas), _p(weight), int(reps), int(threads), C.byref(chk))
+    return int(used), float(chk.value)
+
+
 def markers_jac(sk, q):
     q = _c(q)
     pos = np.empty((sk.n_markers, 3))
