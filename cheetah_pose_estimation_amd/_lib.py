@@ -69,6 +69,7 @@ def load():
     lib.cpe_forward_kinematics.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
     lib.cpe_marker_velocities.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
     lib.cpe_reproject.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    lib.cpe_triangulate.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_double, vp]
     lib.cpe_eval_normal.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
@@ -175,6 +176,22 @@ class Handle:
         self.reproject(pd, uv)
         self.synchronize()
         return uv.cpu().numpy()
+
+    def triangulate_host(self, cam_a, cam_b, uv_a, uv_b, depth=3.0):
+        """n detection pairs -> xyz [n, 3] (cpe_triangulate; cam_b < 0: back-projection of uv_a to `depth`); numpy in / out"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        ca = torch.tensor(np.ascontiguousarray(cam_a, dtype=np.int32), device=dev)
+        cb = torch.tensor(np.ascontiguousarray(cam_b, dtype=np.int32), device=dev)
+        ua = torch.tensor(np.ascontiguousarray(uv_a, dtype=np.float64).reshape(-1, 2), device=dev)
+        ub = torch.tensor(np.ascontiguousarray(uv_b, dtype=np.float64).reshape(-1, 2), device=dev)
+        n = int(ca.shape[0])
+        if not (cb.shape[0] == n and ua.shape[0] == n and ub.shape[0] == n):
+            raise CpeError("triangulate_host: array lengths differ")
+        xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        _check(self.lib.cpe_triangulate(self._h, n, _ptr(ca), _ptr(cb), _ptr(ua), _ptr(ub), float(depth), _ptr(xyz)), "cpe_triangulate")
+        self.synchronize()
+        return xyz.cpu().numpy()
 
     def kinematics_host(self, q, dq):
         """numpy in, numpy out (staged through HBM with torch): positions [B, N, L, 3], marker velocities [B, N, L, 3]"""

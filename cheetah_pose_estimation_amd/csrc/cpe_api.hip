@@ -583,6 +583,24 @@ cpe_status cpe_reproject(cpe_handle* h, int32_t B, int32_t N, const double* posi
     return CPE_OK;
 }
 
+cpe_status cpe_triangulate(cpe_handle* h, int32_t n, const int32_t* cam_a, const int32_t* cam_b, const double* uv_a, const double* uv_b,
+                           double depth, double* xyz) {
+    if (!h || !cam_a || !cam_b || !uv_a || !uv_b || !xyz) return fail(CPE_BAD_ARG, "null argument");
+    if (n < 0) return fail(CPE_BAD_ARG, "negative size");
+    if (n == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    // the camera indices select entries of the handle's camera table: check them on the host before any lane dereferences one
+    std::vector<int32_t> ia(n), ib(n);
+    HIPCHK(hipMemcpyAsync(ia.data(), cam_a, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ib.data(), cam_b, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++)
+        if (ia[i] < 0 || ia[i] >= h->hm.C || ib[i] >= h->hm.C) return fail(CPE_BAD_ARG, "camera index out of range");
+    hipLaunchKernelGGL(k_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->dm, n, cam_a, cam_b, uv_a, uv_b, depth, xyz);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
 static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     const size_t F = (size_t)B * N;
     if (F <= h->ws_frames && B <= h->ws_B) return CPE_OK;

@@ -420,6 +420,95 @@ __global__ __launch_bounds__(WAVE) void k_reproject(const DevModel* __restrict__
 }
 
 // --------------------------------------------------------------------------------------------------
+// initial-guess ingestion: undistort two detections and triangulate them linearly (triangulate_points[_fisheye],
+// acinoset_misc.py:1432-1453: cv[.fisheye].undistortPoints + cv.triangulatePoints), one lane per point pair.
+// cam_b < 0: back-projection of the first detection to `depth` along its ray (the monocular rule of the initial
+// trajectory estimate).  Pure register code.
+__device__ __forceinline__ void undistort_pixel(const cpe_camera& c, double u, double v, double& x, double& y) {
+    const double x0 = (u - c.cx) / c.fx, y0 = (v - c.cy) / c.fy;
+    if (c.model == CPE_CAM_FISHEYE) {
+        // theta_d = theta (1 + D0 theta^2 + .. + D3 theta^8) solved for theta by Newton, then (x, y) *= tan(theta) / theta_d
+        const double rd = sqrt(x0 * x0 + y0 * y0);
+        double th = rd;
+        for (int it = 0; it < 20; it++) {
+            const double t2 = th * th;
+            const double f = th * (1.0 + t2 * (c.D[0] + t2 * (c.D[1] + t2 * (c.D[2] + t2 * c.D[3])))) - rd;
+            const double df = 1.0 + t2 * (3.0 * c.D[0] + t2 * (5.0 * c.D[1] + t2 * (7.0 * c.D[2] + t2 * 9.0 * c.D[3])));
+            th -= f / df;
+        }
+        const double sc = rd > 1e-12 ? tan(th) / rd : 1.0;
+        x = x0 * sc; y = y0 * sc;
+    } else {
+        // radial polynomial inverted by the fixed-point iteration of cv.undistortPoints
+        x = x0; y = y0;
+        for (int it = 0; it < 20; it++) {
+            const double r2 = x * x + y * y;
+            const double g = 1.0 + r2 * (c.D[0] + r2 * (c.D[1] + r2 * c.D[2]));
+            x = x0 / g; y = y0 / g;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_triangulate(const DevModel* __restrict__ M, int n, const int* __restrict__ cam_a,
+                                                     const int* __restrict__ cam_b, const double* __restrict__ uv_a,
+                                                     const double* __restrict__ uv_b, double depth, double* __restrict__ xyz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cpe_camera& ca = M->cam[cam_a[i]];
+    double xa, ya;
+    undistort_pixel(ca, uv_a[2 * i], uv_a[2 * i + 1], xa, ya);
+    double X[3];
+    if (cam_b[i] < 0) {
+        // X = R^T (depth (x, y, 1) - t)
+        const double w[3] = {depth * xa - ca.t[0], depth * ya - ca.t[1], depth - ca.t[2]};
+        for (int k = 0; k < 3; k++) X[k] = ca.R[k] * w[0] + ca.R[3 + k] * w[1] + ca.R[6 + k] * w[2];
+    } else {
+        const cpe_camera& cb = M->cam[cam_b[i]];
+        double xb, yb;
+        undistort_pixel(cb, uv_b[2 * i], uv_b[2 * i + 1], xb, yb);
+        // rows of A: x P[2] - P[0], y P[2] - P[1] for both views, P = [R | t]; the solution is the right singular vector of
+        // the smallest singular value = eigenvector of the smallest eigenvalue of A^T A (cyclic Jacobi, 4 x 4)
+        double A[4][4];
+        for (int k = 0; k < 4; k++) {
+            const double a0 = k < 3 ? ca.R[k] : ca.t[0], a1 = k < 3 ? ca.R[3 + k] : ca.t[1], a2 = k < 3 ? ca.R[6 + k] : ca.t[2];
+            const double b0 = k < 3 ? cb.R[k] : cb.t[0], b1 = k < 3 ? cb.R[3 + k] : cb.t[1], b2 = k < 3 ? cb.R[6 + k] : cb.t[2];
+            A[0][k] = xa * a2 - a0; A[1][k] = ya * a2 - a1; A[2][k] = xb * b2 - b0; A[3][k] = yb * b2 - b1;
+        }
+        double S[4][4], V[4][4];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                S[r][c] = A[0][r] * A[0][c] + A[1][r] * A[1][c] + A[2][r] * A[2][c] + A[3][r] * A[3][c];
+                V[r][c] = r == c ? 1.0 : 0.0;
+            }
+        for (int sweep = 0; sweep < 12; sweep++)
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int q = p + 1; q < 4; q++) {
+                    const double apq = S[p][q];
+                    if (fabs(apq) < 1e-300) continue;
+                    const double tau = (S[q][q] - S[p][p]) / (2.0 * apq);
+                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const double skp = S[k][p], skq = S[k][q]; S[k][p] = cs * skp - sn * skq; S[k][q] = sn * skp + cs * skq; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const double spk = S[p][k], sqk = S[q][k]; S[p][k] = cs * spk - sn * sqk; S[q][k] = sn * spk + cs * sqk; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = cs * vkp - sn * vkq; V[k][q] = sn * vkp + cs * vkq; }
+                }
+        int m = 0;
+#pragma unroll
+        for (int k = 1; k < 4; k++) if (S[k][k] < S[m][m]) m = k;
+        double h[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = m == 0 ? V[k][0] : m == 1 ? V[k][1] : m == 2 ? V[k][2] : V[k][3];
+        for (int k = 0; k < 3; k++) X[k] = h[k] / h[3];
+    }
+    xyz[3 * i] = X[0]; xyz[3 * i + 1] = X[1]; xyz[3 * i + 2] = X[2];
+}
+
+// --------------------------------------------------------------------------------------------------
 // dependent-angle projection in place.  dynamic LDS: q[nq] | sc[6 nl]
 __global__ __launch_bounds__(WAVE) void k_project(const DevModel* __restrict__ M, double* __restrict__ q,
                                                   int* __restrict__ clamped_flag) {

@@ -152,49 +152,14 @@ def scene_cameras(scene: Scene, kinetic_dataset: bool):
     return cams
 
 
-# ---- initial guess (acinoset_misc.py:381-456): host side, once per sequence ---------------------------
-def _undistort_fisheye(uv, K, D):
-    """inverse of the fisheye model of acinoset_misc.py:1663-1679 (what cv.fisheye.undistortPoints returns)"""
-    x = (uv[:, 0] - K[0, 2]) / K[0, 0]; y = (uv[:, 1] - K[1, 2]) / K[1, 1]
-    rd = np.sqrt(x * x + y * y)
-    th = rd.copy()
-    for _ in range(20):
-        t2 = th * th
-        f = th * (1 + D[0] * t2 + D[1] * t2**2 + D[2] * t2**3 + D[3] * t2**4) - rd
-        df = 1 + 3 * D[0] * t2 + 5 * D[1] * t2**2 + 7 * D[2] * t2**3 + 9 * D[3] * t2**4
-        th = th - f / df
-    s = np.where(rd > 1e-12, np.tan(th) / np.maximum(rd, 1e-12), 1.0)
-    return np.stack([x * s, y * s], axis=1)
-
-
-def _undistort_pinhole(uv, K, D):
-    x0 = (uv[:, 0] - K[0, 2]) / K[0, 0]; y0 = (uv[:, 1] - K[1, 2]) / K[1, 1]
-    x, y = x0.copy(), y0.copy()
-    for _ in range(20):
-        r2 = x * x + y * y
-        g = 1 + D[0] * r2 + D[1] * r2**2 + D[2] * r2**3
-        x, y = x0 / g, y0 / g
-    return np.stack([x, y], axis=1)
-
-
-def _triangulate(n1, n2, R1, t1, R2, t2):
-    """linear (DLT) two-view triangulation of normalised image points, as cv.triangulatePoints"""
-    P1 = np.hstack([R1, t1.reshape(3, 1)]); P2 = np.hstack([R2, t2.reshape(3, 1)])
-    out = np.empty((len(n1), 3))
-    for i in range(len(n1)):
-        A = np.stack([n1[i, 0] * P1[2] - P1[0], n1[i, 1] * P1[2] - P1[1], n2[i, 0] * P2[2] - P2[0], n2[i, 1] * P2[2] - P2[1]])
-        X = np.linalg.svd(A)[2][-1]
-        out[i] = X[:3] / X[3]
-    return out
-
-
-def create_trajectory_estimate(tables, params: TrajectoryParams, scene: Scene, base_length: float):
+# ---- initial guess (acinoset_misc.py:381-456) ------------------------------------------------------------------------
+def create_trajectory_estimate(tables, params: TrajectoryParams, scene: Scene, base_length: float, device: int = 0):
     """x, y, z, psi initial estimate from the `spine` marker (acinoset_misc.py:381-456): pairwise triangulation
-    over the camera ring (multi-view) or back-projection to 3 m depth (monocular), cubic / linear smoothing
-    spline, heading from finite differences (+pi: the skeleton's head points along -x)."""
+    over the camera ring (multi-view) or back-projection to 3 m depth (monocular) -- both on the GPU, cpe_triangulate --
+    then the per-frame mean over the pairs, a cubic / linear smoothing spline, heading from finite differences (+pi: the
+    skeleton's head points along -x)."""
     from scipy.interpolate import UnivariateSpline
     kin = params.kinetic_dataset
-    und = _undistort_pinhole if kin else _undistort_fisheye
     col = skeleton.DLC_INDEX["spine"]
     off = [0] * scene.n_cams
     if params.sync_offset is not None:
@@ -205,31 +170,30 @@ def create_trajectory_estimate(tables, params: TrajectoryParams, scene: Scene, b
         idx, vals = tables[c]
         ok = vals[:, 3 * col + 2] > params.dlc_thresh
         obs[c] = {int(f) + off[c]: vals[i, 3 * col:3 * col + 2] for i, f in enumerate(idx) if ok[i]}
-    pts = {}
+    # one flat list of (frame, camera a, camera b, pixel a, pixel b) records for a single launch
+    rec_f, rec_a, rec_b, rec_ua, rec_ub = [], [], [], [], []
     if scene.cam_idx is None:
         ncam = 2 if kin else scene.n_cams                       # kinetic dataset: near-side cameras only (:399-401)
-        pairs = [(i % ncam, (i + 1) % ncam) for i in range(ncam)]
-        for a, b in pairs:
-            common = sorted(set(obs[a]) & set(obs[b]))
-            if not common:
-                continue
-            ua = np.array([obs[a][f] for f in common], dtype=np.float32).astype(np.float64)
-            ub = np.array([obs[b][f] for f in common], dtype=np.float32).astype(np.float64)
-            X = _triangulate(und(ua, scene.k_arr[a], scene.d_arr[a]), und(ub, scene.k_arr[b], scene.d_arr[b]),
-                             scene.r_arr[a], scene.t_arr[a].ravel(), scene.r_arr[b], scene.t_arr[b].ravel())
-            for f, x in zip(common, X):
-                pts.setdefault(f, []).append(x)
-        frames = np.array(sorted(pts))
-        xyz = np.array([np.mean(pts[f], axis=0) for f in frames])
+        for a, b in [(i % ncam, (i + 1) % ncam) for i in range(ncam)]:
+            for f in sorted(set(obs[a]) & set(obs[b])):
+                rec_f.append(f); rec_a.append(a); rec_b.append(b); rec_ua.append(obs[a][f]); rec_ub.append(obs[b][f])
     else:
         c = scene.cam_idx
-        frames = np.array(sorted(obs[c]))
-        uv = np.array([obs[c][f] for f in frames], dtype=np.float32).astype(np.float64)
-        nrm = und(uv, scene.k_arr[c], scene.d_arr[c])
-        Xc = 3.0 * np.c_[nrm, np.ones(len(nrm))]
-        R, t = scene.r_arr[c], scene.t_arr[c].ravel()
-        xyz = (Xc - t) @ R                                           # R^T (Xc - t)
-    xyz = xyz.copy()
+        for f in sorted(obs[c]):
+            rec_f.append(f); rec_a.append(c); rec_b.append(-1); rec_ua.append(obs[c][f]); rec_ub.append(obs[c][f])
+    if not rec_f:
+        raise ValueError("no usable spine detections for the initial trajectory estimate")
+    f32 = lambda a: np.array(a, dtype=np.float32).astype(np.float64)          # the reference hands float32 pixels to OpenCV (:1467-1468)
+    all_cams = scene_cameras(Scene(scene.scene_fpath, scene.k_arr, scene.d_arr, scene.r_arr, scene.t_arr, scene.cam_res,
+                                   scene.fps, scene.n_cams, None), kin)
+    h = _lib.Handle(skeleton.build_skeleton("phantom", 24), all_cams, device=device)      # only the camera table is used
+    try:
+        X = h.triangulate_host(rec_a, rec_b, f32(rec_ua), f32(rec_ub), depth=3.0)
+    finally:
+        h.close()
+    rec_f = np.array(rec_f)
+    frames = np.unique(rec_f)
+    xyz = np.array([X[rec_f == f].mean(axis=0) for f in frames])             # groupby(frame).mean() (:1491)
     xyz[:, 0] += base_length / 2.0                                   # :424
     k = 1 if kin else 3
     fr = np.arange(params.end_frame)
@@ -419,7 +383,7 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
     N = params.end_frame - params.start_frame
     if q_init is None:
         base_len = 2.0 * abs(sk.marker_off[5][0])
-        x, y, z, psi = create_trajectory_estimate(est.tables, params, scene, base_len)
+        x, y, z, psi = create_trajectory_estimate(est.tables, params, scene, base_len, device=est.device)
         q_init = np.zeros((N, sk.nq))                               # acinoset_opt.py:574-583
         sl = slice(params.start_frame, params.start_frame + N)
         q_init[:, 0], q_init[:, 1], q_init[:, 2] = x[sl], y[sl], z[sl]

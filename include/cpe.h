@@ -274,6 +274,13 @@ cpe_status cpe_marker_velocities(cpe_handle* h, int32_t B, int32_t N, const doub
 cpe_status cpe_reproject(cpe_handle* h, int32_t B, int32_t N, const double* positions /*[B][N][L][3]*/,
                          double* uv /*[B][N][C][L][2]*/);
 
+/* initial-guess ingestion: two-view linear triangulation of n detection pairs, i.e. triangulate_points[_fisheye]
+ * (acinoset_misc.py:1432-1453: cv[.fisheye].undistortPoints of both pixels with the cameras' K and D, cv.triangulatePoints with
+ * [R | t]).  cam_a / cam_b index the handle's cameras; cam_b[i] < 0 asks for the monocular rule instead: the first detection
+ * back-projected to `depth` metres along its ray.  Device ptrs: cam_a, cam_b int32[n]; uv_a, uv_b [n][2]; xyz [n][3]. */
+cpe_status cpe_triangulate(cpe_handle* h, int32_t n, const int32_t* cam_a, const int32_t* cam_b, const double* uv_a, const double* uv_b,
+                           double depth, double* xyz);
+
 #ifdef __cplusplus
 }
 #endif
