@@ -70,6 +70,7 @@ def load():
     lib.cpe_marker_velocities.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
     lib.cpe_reproject.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     lib.cpe_triangulate.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_double, vp]
+    lib.cpe_tensorise_dlc.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp]
     lib.cpe_eval_normal.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
@@ -192,6 +193,26 @@ class Handle:
         _check(self.lib.cpe_triangulate(self._h, n, _ptr(ca), _ptr(cb), _ptr(ua), _ptr(ub), float(depth), _ptr(xyz)), "cpe_triangulate")
         self.synchronize()
         return xyz.cpu().numpy()
+
+    def tensorise_dlc_host(self, tables, first_rows, part_of_marker, inv_sigma, thresh, N):
+        """per-camera DLC tables (numpy [rows, 3*parts]) -> meas [N, C, L, 2], weight [N, C, L] (numpy) through cpe_tensorise_dlc"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        Cn = len(tables)
+        meas = torch.empty((N, Cn, self.L, 2), dtype=torch.float64, device=dev)
+        weight = torch.empty((N, Cn, self.L), dtype=torch.float64, device=dev)
+        pm = torch.tensor(np.ascontiguousarray(part_of_marker, dtype=np.int32), device=dev)
+        isg = torch.tensor(np.ascontiguousarray(inv_sigma, dtype=np.float64), device=dev)
+        if pm.shape[0] != self.L or isg.shape[0] != self.L:
+            raise CpeError("tensorise_dlc_host: one body part and one sigma per marker of the handle")
+        for c, tab in enumerate(tables):
+            t = torch.tensor(np.ascontiguousarray(tab, dtype=np.float64), device=dev)
+            if t.dim() != 2 or t.shape[1] % 3:
+                raise CpeError("tensorise_dlc_host: a DLC table has 3 columns per body part")
+            _check(self.lib.cpe_tensorise_dlc(self._h, N, Cn, c, _ptr(t), int(t.shape[0]), int(t.shape[1] // 3), int(first_rows[c]), _ptr(pm), _ptr(isg),
+                                              float(thresh), _ptr(meas), _ptr(weight)), "cpe_tensorise_dlc")
+            self.synchronize()                      # `t` must outlive the launch
+        return meas.cpu().numpy(), weight.cpu().numpy()
 
     def kinematics_host(self, q, dq):
         """numpy in, numpy out (staged through HBM with torch): positions [B, N, L, 3], marker velocities [B, N, L, 3]"""

@@ -601,6 +601,20 @@ cpe_status cpe_triangulate(cpe_handle* h, int32_t n, const int32_t* cam_a, const
     return CPE_OK;
 }
 
+cpe_status cpe_tensorise_dlc(cpe_handle* h, int32_t N, int32_t n_slots, int32_t slot, const double* table, int32_t rows, int32_t parts,
+                             int32_t first_row, const int32_t* part_of_marker, const double* inv_sigma, double thresh, double* meas, double* weight) {
+    if (!h || !table || !part_of_marker || !inv_sigma || !meas || !weight) return fail(CPE_BAD_ARG, "null argument");
+    if (N < 0 || rows < 0 || parts <= 0) return fail(CPE_BAD_ARG, "bad size");
+    if (n_slots <= 0 || slot < 0 || slot >= n_slots) return fail(CPE_BAD_ARG, "camera slot out of range");
+    if (N == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const long total = (long)N * h->hm.L;
+    hipLaunchKernelGGL(k_tensorise_dlc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, N, h->hm.L, n_slots, slot, table, rows, parts,
+                       first_row, part_of_marker, inv_sigma, thresh, meas, weight);
+    HIPCHK(hipGetLastError());
+    return CPE_OK;
+}
+
 static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     const size_t F = (size_t)B * N;
     if (F <= h->ws_frames && B <= h->ws_B) return CPE_OK;

@@ -509,6 +509,29 @@ __global__ __launch_bounds__(256) void k_triangulate(const DevModel* __restrict_
 }
 
 // --------------------------------------------------------------------------------------------------
+// DeepLabCut table of one camera -> that camera's slice of meas[N][C][L][2] and weight[N][C][L]
+// (init_measurements / init_meas_weights, acinoset_misc.py:211-256).  One lane per (frame, marker): a strided gather.
+__global__ __launch_bounds__(256) void k_tensorise_dlc(int N, int L, int n_slots, int slot, const double* __restrict__ table, int rows,
+                                                       int parts, int first_row, const int* __restrict__ part_of_marker,
+                                                       const double* __restrict__ inv_sigma, double thresh,
+                                                       double* __restrict__ meas, double* __restrict__ weight) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * L) return;
+    const int n = (int)(i / L), l = (int)(i - (long)n * L);
+    const long row = (long)first_row + n;
+    double x = 0.0, y = 0.0, w = 0.0;
+    const int part = part_of_marker[l];
+    if (row >= 0 && row < rows && part >= 0 && part < parts) {
+        const double* v = table + row * (long)(3 * parts) + 3 * part;
+        const double vx = v[0], vy = v[1], lik = v[2];
+        const bool finite = vx == vx && vy == vy && fabs(vx) != INFINITY && fabs(vy) != INFINITY;
+        if (finite) { x = vx; y = vy; if (lik > thresh) w = inv_sigma[l]; }
+    }
+    const long o = ((long)n * n_slots + slot) * L + l;
+    meas[2 * o] = x; meas[2 * o + 1] = y; weight[o] = w;
+}
+
+// --------------------------------------------------------------------------------------------------
 // dependent-angle projection in place.  dynamic LDS: q[nq] | sc[6 nl]
 __global__ __launch_bounds__(WAVE) void k_project(const DevModel* __restrict__ M, double* __restrict__ q,
                                                   int* __restrict__ clamped_flag) {

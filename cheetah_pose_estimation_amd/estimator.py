@@ -105,10 +105,11 @@ def dlc_paths(dlc_dir: str) -> List[str]:
 
 
 def build_measurements(tables, start_frame: int, end_frame: int, sync_offset, n_cams: int, dlc_thresh: float,
-                       kinetic_dataset: bool, cam_idx: Optional[int] = None):
+                       kinetic_dataset: bool, cam_idx: Optional[int] = None, device: int = 0):
     """meas[N,C,24,2] and meas_err_weight[N,C,24] exactly as `init_measurements` / `init_meas_weights` fill the
     Pyomo params (acinoset_misc.py:211-256): row (n + start_frame - sync_offset[c]) of camera c, DLC column of
-    each marker (`get_dlc_marker_indices`), weight 1/R_pw[0][l] if likelihood > dlc_thresh else 0."""
+    each marker (`get_dlc_marker_indices`), weight 1/R_pw[0][l] if likelihood > dlc_thresh else 0.  The gather runs on
+    the GPU (cpe_tensorise_dlc), one launch per camera table."""
     off = [0] * n_cams
     if sync_offset is not None:
         for o in sync_offset:
@@ -116,19 +117,13 @@ def build_measurements(tables, start_frame: int, end_frame: int, sync_offset, n_
     N = end_frame - start_frame
     cams = list(range(n_cams)) if cam_idx is None else [cam_idx]
     sigma = skeleton.measurement_sigma(24, kinetic_dataset)
-    col = np.array([skeleton.DLC_INDEX[m] for m in skeleton.MARKERS])
-    meas = np.zeros((N, len(cams), 24, 2)); weight = np.zeros((N, len(cams), 24))
-    for ci, c in enumerate(cams):
-        vals = tables[c][1]
-        rows = np.arange(N) + start_frame - off[c]
-        v = vals[rows]
-        x, y, lik = v[:, 0::3][:, col], v[:, 1::3][:, col], v[:, 2::3][:, col]
-        ok = lik > dlc_thresh
-        weight[:, ci] = np.where(ok, 1.0 / sigma[None, :], 0.0)
-        meas[:, ci, :, 0] = np.where(np.isfinite(x), x, 0.0)
-        meas[:, ci, :, 1] = np.where(np.isfinite(y), y, 0.0)
-        weight[:, ci][~(np.isfinite(x) & np.isfinite(y))] = 0.0
-    return meas, weight
+    col = [skeleton.DLC_INDEX[m] for m in skeleton.MARKERS]
+    from .synth import make_cameras
+    h = _lib.Handle(skeleton.build_skeleton("phantom", 24), make_cameras(1), device=device)        # only the marker count is used
+    try:
+        return h.tensorise_dlc_host([tables[c][1] for c in cams], [start_frame - off[c] for c in cams], col, 1.0 / sigma, dlc_thresh, N)
+    finally:
+        h.close()
 
 
 def scene_cameras(scene: Scene, kinetic_dataset: bool):
@@ -357,7 +352,7 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
     assert n_cams == len(paths), f"# of dlc files != # of cams in {scene_fpath}"
     tables = [load_dlc_table(p) for p in paths]
     sk = skeleton.build_skeleton(model_name, 24, kinetic_dataset)
-    meas, weight = build_measurements(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx)
+    meas, weight = build_measurements(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx, device=device)
     total_mass = sum(sk.mass[i] for i in range(sk.n_links))
     return CheetahEstimator(cheetah_name, data_path, params, scene, sk, scene_cameras(scene, kinetic_dataset), meas, weight,
                             total_mass * 9.81, kinematic_model, tables, device)

@@ -281,6 +281,14 @@ cpe_status cpe_reproject(cpe_handle* h, int32_t B, int32_t N, const double* posi
 cpe_status cpe_triangulate(cpe_handle* h, int32_t n, const int32_t* cam_a, const int32_t* cam_b, const double* uv_a, const double* uv_b,
                            double depth, double* xyz);
 
+/* measurement ingestion: the DeepLabCut table of ONE camera -> that camera's slice `slot` of meas [N][n_slots][L][2]
+ * and weight [N][n_slots][L], as init_measurements / init_meas_weights fill the Pyomo params (acinoset_misc.py:211-256): frame n
+ * reads table row first_row + n (first_row = start_frame - sync_offset of the camera), marker l reads body part part_of_marker[l];
+ * weight = inv_sigma[l] if likelihood > thresh else 0.  Rows outside the table and non-finite coordinates give meas 0, weight 0.
+ * table [rows][3*parts] = (x, y, likelihood) per body part; L is the handle's marker count.  Device ptrs. */
+cpe_status cpe_tensorise_dlc(cpe_handle* h, int32_t N, int32_t n_slots, int32_t slot, const double* table, int32_t rows, int32_t parts,
+                             int32_t first_row, const int32_t* part_of_marker, const double* inv_sigma, double thresh, double* meas, double* weight);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,9 @@ from dataset_util import write_dataset
 
 
 def test_scene_dlc_and_measurement_tensors(tmp_path):
+    """file formats in (scene file, DLC tables) and the tensorisation rule, on the numpy checker of cpe_tensorise_dlc
+    (dataset_util.build_measurements_numpy); the device version is compared with it in tests/test_gpu_parity.py"""
+    from dataset_util import build_measurements_numpy
     info = write_dataset(str(tmp_path), N=20)
     import os
     ddir = os.path.join(str(tmp_path), info["data_path"])
@@ -15,7 +18,7 @@ def test_scene_dlc_and_measurement_tensors(tmp_path):
     assert n_cams == 6 and res == (synth.IMG_W, synth.IMG_H) and k.shape == (6, 3, 3) and d.reshape(6, -1).shape == (6, 4)
     tables = [E.load_dlc_table(p) for p in E.dlc_paths(os.path.join(ddir, "dlc"))]
     assert len(tables) == 6 and tables[0][1].shape == (28, 75)
-    meas, weight = E.build_measurements(tables, 4, 24, [{"cam": 1, "frame": 2}], 6, 0.5, False)
+    meas, weight = build_measurements_numpy(tables, 4, 24, [{"cam": 1, "frame": 2}], 6, 0.5, False)
     assert meas.shape == (20, 6, 24, 2) and weight.shape == (20, 6, 24)
     sig = skeleton.measurement_sigma(24)
     for l, m in enumerate(skeleton.MARKERS):
@@ -25,8 +28,8 @@ def test_scene_dlc_and_measurement_tensors(tmp_path):
         lik = tables[0][1][4:24, 3 * j + 2]
         assert np.array_equal(weight[:, 0, l], np.where(lik > 0.5, 1.0 / sig[l], 0.0))
     # monocular selection keeps one camera
-    m1, w1 = E.build_measurements(tables, 4, 24, None, 6, 0.5, False, cam_idx=2)
-    assert m1.shape == (20, 1, 24, 2) and np.array_equal(m1[:, 0], E.build_measurements(tables, 4, 24, None, 6, 0.5, False)[0][:, 2])
+    m1, w1 = build_measurements_numpy(tables, 4, 24, None, 6, 0.5, False, cam_idx=2)
+    assert m1.shape == (20, 1, 24, 2) and np.array_equal(m1[:, 0], build_measurements_numpy(tables, 4, 24, None, 6, 0.5, False)[0][:, 2])
 
 
 def test_initial_guess_checker_identities():

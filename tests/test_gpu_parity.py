@@ -600,6 +600,26 @@ def test_triangulation_matches_checker(sk25, gpu_handle_factory):
         h.triangulate_host([0, 9], [1, 1], ua[:2], ub[:2])              # camera index outside the handle's table
 
 
+def test_measurement_tensorisation_matches_checker(tmp_path):
+    """cpe_tensorise_dlc through estimator.build_measurements against the numpy checker: sync offsets, likelihood threshold,
+    monocular selection, rows outside the table and NaN detections"""
+    import os
+    from cheetah_pose_estimation_amd import estimator as E
+    from dataset_util import write_dataset, build_measurements_numpy
+    info = write_dataset(str(tmp_path), N=20)
+    ddir = os.path.join(str(tmp_path), info["data_path"])
+    tables = [E.load_dlc_table(p) for p in E.dlc_paths(os.path.join(ddir, "dlc"))]
+    tables[3][1][7, 12] = np.nan                                          # a missing detection
+    for args in ((4, 24, [{"cam": 1, "frame": 2}], 6, 0.5, False), (4, 24, None, 6, 0.8, True), (20, 40, None, 6, 0.5, False)):
+        got = E.build_measurements(tables, *args)
+        want = build_measurements_numpy(tables, *args)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), args
+    assert (want[1][8:] == 0).all() and (want[1][:8] > 0).any()           # frames 28.. lie beyond the 28 table rows
+    g1 = E.build_measurements(tables, 4, 24, None, 6, 0.5, False, cam_idx=2)
+    w1 = build_measurements_numpy(tables, 4, 24, None, 6, 0.5, False, cam_idx=2)
+    assert g1[0].shape == (20, 1, 24, 2) and np.array_equal(g1[0], w1[0]) and np.array_equal(g1[1], w1[1])
+
+
 def test_initial_trajectory_estimate(tmp_path):
     """create_trajectory_estimate (acinoset_misc.py:381-456) from DLC files: device triangulation + host spline"""
     import os
