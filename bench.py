@@ -90,7 +90,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed launches; the clocks of an idle MI355X need ~10 launches (30 ms) to ramp")
     ap.add_argument("--batch", type=int, default=2048, help="sequences per GPU for the residual+Jacobian pass")
     ap.add_argument("--solve-batch", type=int, default=2048, help="sequences per GPU for the solve timing")
     ap.add_argument("--markers", type=int, default=25)
