@@ -115,7 +115,7 @@ def default_options(fps: float = 120.0) -> Options:
     o.max_outer = 8
     o.lambda0 = 1e-4
     o.tol_step = 1e-8
-    o.tol_cost = 1e-12
+    o.tol_cost = 1e-9
     o.max_iter = 200
     o.curvature = 0
     return o

@@ -336,7 +336,7 @@ const char* cpe_last_error(void) { return g_err.c_str(); }
 
 void cpe_default_options(cpe_options* o) {
     o->h = 1.0 / 120.0; o->loss_a = 3.0; o->loss_b = 10.0; o->loss_c = 20.0; o->cost_scale = 1e-3;
-    o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-4; o->tol_step = 1e-8; o->tol_cost = 1e-12; o->max_iter = 200;
+    o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-4; o->tol_step = 1e-8; o->tol_cost = 1e-9; o->max_iter = 200;
     o->curvature = 0; o->max_outer = 8; o->_pad = 0;
 }
 

@@ -1196,6 +1196,6 @@ void cpo_grf_fit_frame(const cpe_skeleton* s, const cpe_grf_options* o, const do
 
 void cpo_default_options(cpe_options* o) {
     o->h = 1.0 / 120; o->loss_a = 3; o->loss_b = 10; o->loss_c = 20; o->cost_scale = 1e-3;
-    o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-4; o->tol_step = 1e-8; o->tol_cost = 1e-12;
+    o->bound_penalty = 1e4; o->bound_tol = 1e-6; o->lambda0 = 1e-4; o->tol_step = 1e-8; o->tol_cost = 1e-9;
     o->max_iter = 200; o->curvature = 0; o->max_outer = 8;
 }

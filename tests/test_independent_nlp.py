@@ -76,3 +76,26 @@ def test_full_space_slsqp_agrees_with_reduced_lm(oracle):
     p_s, _ = synth.fk_numpy(sk, sol.x.reshape(N, sk.nq))
     rmse = np.sqrt(((p_s - res["positions"]) ** 2).sum(-1).mean())
     assert rmse < 1e-4, rmse
+
+
+def test_default_stopping_tolerance_is_far_inside_the_1mm_bar(oracle):
+    """The default `tol_cost` (relative cost decrease 1e-9; the reference runs IPOPT with Tol = 1e-3, acinoset_opt.py:611-617) against a
+    solve carried to 1e-12 (the previous default): marker trajectories agree to hundredths of a millimetre, two orders of magnitude inside BASELINE.json's
+    1 mm RMSE bar, and the default saves iterations."""
+    sk = skeleton.build_skeleton("phantom", 25)
+    cams = synth.make_cameras(6)
+    its = {}
+    for seed in (77, 1238):
+        d = synth.make_batch(sk, cams, B=1, N=60, seed=seed)
+        sol = {}
+        for tol in (None, 1e-12):
+            opts = abi.default_options()
+            assert opts.tol_cost == 1e-9
+            if tol is not None:
+                opts.tol_cost = tol
+            sol[tol] = oracle.solve(sk, cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+            assert sol[tol]["stats"].status == abi.OK
+            its[tol] = its.get(tol, 0) + sol[tol]["stats"].iterations
+        dev = np.sqrt(((sol[None]["positions"] - sol[1e-12]["positions"]) ** 2).sum(-1))
+        assert np.sqrt((dev ** 2).mean()) < 5e-5 and dev.max() < 5e-4, (seed, dev.max())
+    assert its[None] < its[1e-12]
