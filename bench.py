@@ -168,7 +168,7 @@ def main():
         J = torch.empty((B, N, C, h24.S, 2), dtype=torch.float64, device=dev)
         eps = torch.empty((B, N, sk24.nq), dtype=torch.float64, device=dev)
         s24 = torch.cuda.ExternalStream(h24.stream, device=dev)
-        for _ in range(2):
+        for _ in range(max(2, args.warmup)):
             h24.eval_resjac(t24["q_true"], t24["meas"], t24["weight"], r, J, eps, None)
         h24.synchronize()
         e24 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
