@@ -559,10 +559,11 @@ cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const dou
 }
 
 cpe_status cpe_marker_velocities(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* dq, double* velocities) {
-    if (!h || !q || !dq || !velocities) return fail(CPE_BAD_ARG, "null argument");
+    if (!h) return fail(CPE_BAD_ARG, "null argument");
     if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
     const size_t F = (size_t)B * N;
     if (F == 0) return CPE_OK;
+    if (!q || !dq || !velocities) return fail(CPE_BAD_ARG, "null argument");
     if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
     HIPCHK(hipSetDevice(h->device));
     const size_t lds = sizeof(double) * (2 * h->hm.nq + 6 * h->hm.nl + 36 * h->hm.nl);
@@ -572,10 +573,11 @@ cpe_status cpe_marker_velocities(cpe_handle* h, int32_t B, int32_t N, const doub
 }
 
 cpe_status cpe_reproject(cpe_handle* h, int32_t B, int32_t N, const double* positions, double* uv) {
-    if (!h || !positions || !uv) return fail(CPE_BAD_ARG, "null argument");
+    if (!h) return fail(CPE_BAD_ARG, "null argument");
     if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
     const size_t F = (size_t)B * N;
     if (F == 0) return CPE_OK;
+    if (!positions || !uv) return fail(CPE_BAD_ARG, "null argument");
     if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_reproject, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, positions, uv);
@@ -585,9 +587,10 @@ cpe_status cpe_reproject(cpe_handle* h, int32_t B, int32_t N, const double* posi
 
 cpe_status cpe_triangulate(cpe_handle* h, int32_t n, const int32_t* cam_a, const int32_t* cam_b, const double* uv_a, const double* uv_b,
                            double depth, double* xyz) {
-    if (!h || !cam_a || !cam_b || !uv_a || !uv_b || !xyz) return fail(CPE_BAD_ARG, "null argument");
+    if (!h) return fail(CPE_BAD_ARG, "null argument");
     if (n < 0) return fail(CPE_BAD_ARG, "negative size");
-    if (n == 0) return CPE_OK;
+    if (n == 0) return CPE_OK;                      // empty input: the arrays may be null
+    if (!cam_a || !cam_b || !uv_a || !uv_b || !xyz) return fail(CPE_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
     // the camera indices select entries of the handle's camera table: check them on the host before any lane dereferences one
     std::vector<int32_t> ia(n), ib(n);
@@ -603,10 +606,11 @@ cpe_status cpe_triangulate(cpe_handle* h, int32_t n, const int32_t* cam_a, const
 
 cpe_status cpe_tensorise_dlc(cpe_handle* h, int32_t N, int32_t n_slots, int32_t slot, const double* table, int32_t rows, int32_t parts,
                              int32_t first_row, const int32_t* part_of_marker, const double* inv_sigma, double thresh, double* meas, double* weight) {
-    if (!h || !table || !part_of_marker || !inv_sigma || !meas || !weight) return fail(CPE_BAD_ARG, "null argument");
+    if (!h) return fail(CPE_BAD_ARG, "null argument");
     if (N < 0 || rows < 0 || parts <= 0) return fail(CPE_BAD_ARG, "bad size");
     if (n_slots <= 0 || slot < 0 || slot >= n_slots) return fail(CPE_BAD_ARG, "camera slot out of range");
     if (N == 0) return CPE_OK;
+    if (!part_of_marker || !inv_sigma || !meas || !weight || (!table && rows > 0)) return fail(CPE_BAD_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
     const long total = (long)N * h->hm.L;
     hipLaunchKernelGGL(k_tensorise_dlc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, N, h->hm.L, n_slots, slot, table, rows, parts,

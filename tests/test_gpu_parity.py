@@ -451,6 +451,21 @@ def test_error_behaviour_of_the_abi(sk25, cams6, gpu_handle_factory):
         _lib.Handle(skeleton.build_skeleton("phantom", 24), cams6, None, pr)
     with pytest.raises(_lib.CpeError):
         _lib.Handle(sk25, cams6, device=99)
+    # the ingestion / output entry points: null pointers, empty inputs, slots outside the tensor
+    assert lib.cpe_triangulate(h._h, 3, None, None, None, None, 3.0, None) == abi.BAD_ARG
+    assert lib.cpe_reproject(h._h, 1, 1, None, None) == abi.BAD_ARG
+    assert lib.cpe_marker_velocities(h._h, 1, -2, None, None, None) == abi.BAD_ARG
+    assert lib.cpe_marker_velocities(h._h, 0, 5, None, None, None) == abi.OK           # empty batch: nothing to touch
+    assert h.triangulate_host([], [], np.zeros((0, 2)), np.zeros((0, 2))).shape == (0, 3)
+    assert h.reproject_host(np.zeros((0, 4, 25, 3))).shape == (0, 4, 6, 25, 2)
+    import torch
+    t = torch.zeros((5, 75), dtype=torch.float64, device="cuda:0"); m = torch.zeros((2, 1, 25, 2), dtype=torch.float64, device="cuda:0")
+    w = torch.zeros((2, 1, 25), dtype=torch.float64, device="cuda:0"); pm = torch.zeros(25, dtype=torch.int32, device="cuda:0")
+    sg = torch.ones(25, dtype=torch.float64, device="cuda:0")
+    args = lambda n_slots, slot, parts: (h._h, 2, n_slots, slot, t.data_ptr(), 5, parts, 0, pm.data_ptr(), sg.data_ptr(), 0.5, m.data_ptr(), w.data_ptr())
+    assert lib.cpe_tensorise_dlc(*args(1, 1, 25)) == abi.BAD_ARG and b"slot" in lib.cpe_last_error()
+    assert lib.cpe_tensorise_dlc(*args(1, 0, 0)) == abi.BAD_ARG
+    assert lib.cpe_tensorise_dlc(*args(1, 0, 25)) == abi.OK
 
 
 @pytest.mark.parametrize("C", [1, 2, 8])
