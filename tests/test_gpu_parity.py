@@ -451,6 +451,13 @@ def test_error_behaviour_of_the_abi(sk25, cams6, gpu_handle_factory):
         _lib.Handle(skeleton.build_skeleton("phantom", 24), cams6, None, pr)
     with pytest.raises(_lib.CpeError):
         _lib.Handle(sk25, cams6, device=99)
+    # sizes beyond the compiled-in maxima (cpe.h CPE_MAX_*) are refused at creation
+    with pytest.raises(_lib.CpeError):
+        _lib.Handle(sk25, synth.make_cameras(9))
+    too_many = skeleton.build_skeleton("phantom", 25)
+    too_many.n_markers = 33
+    with pytest.raises(_lib.CpeError):
+        _lib.Handle(too_many, cams6)
     # the ingestion / output entry points: null pointers, empty inputs, slots outside the tensor
     assert lib.cpe_triangulate(h._h, 3, None, None, None, None, 3.0, None) == abi.BAD_ARG
     assert lib.cpe_reproject(h._h, 1, 1, None, None) == abi.BAD_ARG
