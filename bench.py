@@ -108,11 +108,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # CPE_BENCH_REHEARSAL=1: rehearse the multi-rank path on a ONE-GPU box -- every rank uses cuda:0 and the two collectives
+    # (timing barrier, MAX over ranks) go over gloo.  The numbers of such a run mean nothing; it checks the plumbing.
+    rehearsal = os.environ.get("CPE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL; used for the timing barrier and the MAX over ranks only
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the timing barrier and the MAX over ranks only
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     L, N, C = args.markers, args.frames, 6
     sk = skeleton.build_skeleton("phantom", L)
@@ -149,10 +164,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed)
     frames_total = world * B * N * args.steps
     value = frames_total / elapsed
 
@@ -196,10 +208,7 @@ def main():
         st, stats = h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)
         barrier()
         el = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
+        el = max_over_ranks(el)
         its = np.array([s.iterations for s in stats])
         stt = np.array([s.status for s in stats])
         solves = dict(value=world * Bs / el, unit="solves/s", batch_per_gpu=Bs, seconds=el, iterations_mean=float(its.mean()),
