@@ -508,7 +508,7 @@ cpe_status cpe_grf_fit(cpe_handle* h, const cpe_grf_options* opt, int32_t B, int
     const size_t F = (size_t)B * N;
     if (F == 0) return CPE_OK;
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_grf, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, *opt, F, q, dq, ddq, contact, grfz, grfxy, residual);
+    hipLaunchKernelGGL(k_grf, dim3((unsigned)((F + GRF_PACK - 1) / GRF_PACK)), dim3(WAVE), 0, h->stream, h->dm, *opt, F, q, dq, ddq, contact, grfz, grfxy, residual);
     HIPCHK(hipGetLastError());
     return CPE_OK;
 }
