@@ -145,8 +145,12 @@ typedef struct cpe_handle cpe_handle;
 cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t n_cams,
                       const cpe_options* opts, const cpe_priors* priors, int32_t device,
                       cpe_handle** out);
+/* frees everything cpe_create allocated (the reference drops its Pyomo model and calls gc.collect() between sequences,
+ * run_dataset.py:1145-1231) */
 void cpe_destroy(cpe_handle* h);
+/* text of the last failure on this thread's most recent call (the reference raises Python exceptions, acinoset_opt.py:400-406) */
 const char* cpe_last_error(void);
+/* the values the reference hard-codes: loss knots (3, 10, 20) acinoset_misc.py:2001-2015, fps-derived h acinoset_opt.py:483-487 */
 void cpe_default_options(cpe_options* o);
 /* stream the handle launches on (hipStream_t as void*), for event timing by the caller */
 void* cpe_stream(cpe_handle* h);
@@ -155,9 +159,10 @@ cpe_status cpe_synchronize(cpe_handle* h);
 /* number of Jacobian slots: the structurally non-zero (marker, dof) pairs, sum_l (3 + 3*chain_len(l)), followed by 0-3
  * structurally ZERO pairs (marker 0, a dof outside its chain; the stored value is 0) that round the count up to a multiple of 4,
  * so that every camera row of J starts on a 64-byte line */
-int32_t cpe_jacobian_slots(const cpe_handle* h);
+int32_t cpe_jacobian_slots(const cpe_handle* h);       /* (the non-zeros of d measurement_constraints / dq, acinoset_misc.py:278-288) */
 /* slot -> (marker, dof) tables; caller provides int32[cpe_jacobian_slots] each */
 cpe_status cpe_jacobian_layout(const cpe_handle* h, int32_t* slot_marker, int32_t* slot_dof);
+/* the reduced coordinates x of get_relative_angles + get_relative_angle_mask (acinoset_misc.py:487-528, :1699-1757) */
 int32_t cpe_num_independent(const cpe_handle* h);                      /* 28 */
 cpe_status cpe_independent_dofs(const cpe_handle* h, int32_t* dofs);   /* q index of each reduced coordinate */
 
@@ -174,6 +179,7 @@ cpe_status cpe_eval_resjac(cpe_handle* h, int32_t B, int32_t N, const double* q,
 
 /* ---- dependent-angle projection: closed-form solve of the 26 joint equalities for the 26 dependent
  * angles given the 28 independent ones (in place on q[B][N][nq], device pointer). */
+/* (the `angle_constraints` of the .robot model, created by add_revolute_joint / add_hookes_joint, cheetah.py:71-72,101,160-161) */
 cpe_status cpe_project_joints(cpe_handle* h, int32_t B, int32_t N, double* q);
 
 /* ---- building block of the solver: per-frame terms in the reduced coordinates at the Euler
@@ -181,6 +187,8 @@ cpe_status cpe_project_joints(cpe_handle* h, int32_t B, int32_t N, double* q);
  * Device pointers.  g [B][N][28]; Bm [B][N][28][28] (measurement + bound + pose-prior Gauss-Newton block);
  * cost [B][N][3] = {robust measurement cost, bound term, pose-prior term}; gam [B][N][nrev][4] = d theta_leg / d(alpha, phi_B, theta_B, psi_B);
  * q_out [B][N][nq] = the consistent Euler angles.  gam and q_out may be NULL. */
+/* (per frame, what ASL hands IPOPT for measurement_cost acinoset_misc.py:459-484, the angle bounds cheetah.py:306-352 and
+ * gmm_pose_cost acinoset_misc.py:680-714: value, gradient and Hessian block) */
 cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
                            double* g, double* Bm, double* cost, double* gam, double* q_out);
 
@@ -194,7 +202,8 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
                      const double* weight, double* q, double* dq, double* ddq, double* positions,
                      double* meas_err, cpe_stats* stats);
 
-/* host-pointer convenience wrappers (stage through HBM; PCIe-inclusive) */
+/* host-pointer convenience wrappers of cpe_eval_resjac / cpe_solve above (same reference counterparts: acinoset_misc.py:269-288,
+ * acinoset_opt.py:611-617); they stage through HBM, so their rates are PCIe-inclusive */
 cpe_status cpe_eval_resjac_host(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas,
                                 const double* weight, double* r, double* J, double* eps, double* cost);
 cpe_status cpe_solve_host(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas,
@@ -224,6 +233,7 @@ typedef struct cpe_grf_options {
 
 /* q, dq, ddq [B][N][nq]; contact [B][N][n_feet] (0 / 1); grfz [B][N][n_feet]; grfxy [B][N][n_feet][4];
  * residual [B][N][6] = rows - B at the solution, in units of M g (may be NULL).  Device pointers. */
+/* CheetahEstimator.estimate_grf, acinoset_opt.py:176-270 (one IPOPT launch per frame there) */
 cpe_status cpe_grf_fit(cpe_handle* h, const cpe_grf_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
                        const double* ddq, const int32_t* contact, double* grfz, double* grfxy, double* residual);
 
@@ -239,6 +249,7 @@ typedef struct cpe_eom_options {
     double gravity;
     double link_inertia[CPE_MAX_LINKS][3];
 } cpe_eom_options;
+/* the lambdified equations of motion `eom_f` of the .robot model (acinoset_opt.py:120-161, :510-514) evaluated at (q, dq, ddq) */
 cpe_status cpe_eom_rows(cpe_handle* h, const cpe_eom_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
                         const double* ddq, double* rows);
 
@@ -258,6 +269,7 @@ typedef struct cpe_dyn_options {
 } cpe_dyn_options;
 /* tau [B][N][n_motors], lambda [B][N][n_constraints], grf [B][N][n_feet][5] = (z, +x, +y, -x, -y) per foot; any may be NULL (= 0).
  * residual [B][N][nq].  Device pointers. */
+/* `slack_eom` of make_pyomo_model(include_eom_slack=True) (acinoset_opt.py:510-514; cost misc.eom_slack_cost, acinoset_misc.py:631) */
 cpe_status cpe_eom_residual(cpe_handle* h, const cpe_dyn_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
                             const double* ddq, const double* tau, const double* lambda, const double* grf, double* residual);
 
