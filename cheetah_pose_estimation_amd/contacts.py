@@ -6,7 +6,8 @@ acinoset_misc.py:745-862 (contact_detection), :865-943 (synth_grf_data) and the 
 their index conventions, so that the files written here can be consumed where the reference's are.
 
 `pe.foot.Foot3D.ground_plane_height` lives in the un-vendored `physical_education` submodule; the ground is z = 0 in
-every stored reconstruction, which is the default used here (parity of that constant: unpinned).
+every stored reconstruction, which is the default used here (parity of that constant: unpinned).  The helper functions below
+are pinned by the outputs of the reference's own helpers (tests/golden/contacts_metrics_*, tools/gen_golden.py).
 """
 import json
 import os

@@ -9,7 +9,8 @@ tests/golden/misc_golden.npz.  Only numbers are committed -- no reference source
 
 Functions exercised (acinoset_misc.py): pt3d_to_2d_fisheye :1663, pt3d_to_2d :1682, redescending_loss
 :2001, get_uncertainty_models :1760, get_relative_angles :487 (numpy branch), get_relative_angle_mask
-:1699, get_markers :1914, get_dlc_marker_indices :1943, get_pairwise_graph :1972, rmse/traj_error :1170-1199.
+:1699, get_markers :1914, get_dlc_marker_indices :1943, get_pairwise_graph :1972, rmse :93-98; into a second file: the contact
+helpers (:69-90, :2033-2057) and traj_smoothness / traj_error (:1170-1199).
 """
 import json
 import math
@@ -102,6 +103,48 @@ def main():
     out.update(metric_a=a, metric_b=b, metric_rmse=float(misc.rmse(a, b)))
     os.makedirs(OUT, exist_ok=True)
     np.savez(os.path.join(OUT, "misc_golden.npz"), **out)
+    # ---- helpers of the contact heuristic and the trajectory metrics (second file; the first one stays byte-identical) ----
+    # acinoset_misc.py: SimpleLinearModel :69-81, bound_value :84-90, positive_zero_crossings :2033-2046,
+    # group_by_consecutive_values :2049-2051, find_minimum_foot_height :2054-2057, traj_smoothness :1170-1176, traj_error :1179-1199
+    rng2 = np.random.default_rng(20241009)
+    aux, lists = {}, {}
+    for name, pts in (("stance", [[9.0, 0.09], [14.0, 0.06]]), ("lfl", [[9.0, 2.0], [15.0, 1.8]]), ("lhl", [[9.0, 2.1], [15.0, 2.6]]),
+                      ("nlfl", [[9.5, 2.1], [15.0, 2.0]]), ("nlhl", [[9.0, 1.7], [15.0, 2.5]])):
+        mdl = misc.SimpleLinearModel(pts)
+        aux[f"line_{name}"] = np.array([mdl.m, mdl.c, mdl.predict(11.3)], dtype=float)
+    vals = np.array([2.5, -1.25, 0.0, 1e-3, -7.0])
+    aux["bound_in"] = vals
+    aux["bound_out"] = np.array([misc.bound_value(float(v), 0.2) for v in vals], dtype=float)
+    series = []
+    for k in range(4):
+        v = np.sin(np.linspace(0, 9 + k, 70) + 0.3 * k) + 0.1 * rng2.normal(size=70)
+        v[rng2.integers(0, 70, 6)] = 0.0                      # exact zeros are dropped before the sign test
+        cnt, idx = misc.positive_zero_crossings(v)
+        series.append(v)
+        lists[f"zc_{k}"] = dict(count=int(cnt), idx=[int(i) for i in idx])
+    aux["zc_series"] = np.array(series)
+    for k, arr in enumerate(([3, 4, 5, 9, 10, 14], [0], [2, 3, 7, 8, 9, 20, 22, 23], [])):
+        lists[f"runs_{k}"] = dict(inp=[int(a) for a in arr], out=[[int(a) for a in run] for run in misc.group_by_consecutive_values(np.array(arr, dtype=int))])
+    h = rng2.uniform(0, 0.3, 50)
+    aux["minh_series"] = h
+    regions = [(0, 50), (10, 30), (25, -1), (40, 45)]
+    aux["minh_regions"] = np.array(regions)
+    aux["minh_out"] = np.array([misc.find_minimum_foot_height(h, r) for r in regions], dtype=np.int64)
+    X = rng2.normal(size=(12, 24, 3)).cumsum(axis=0) * 0.05
+    Y = X + rng2.normal(0, 0.02, X.shape)
+    aux["traj_X"], aux["traj_Y"] = X, Y
+    aux["traj_smoothness"] = np.array(misc.traj_smoothness(X, Y))
+    for centered in (False, True):
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            res, per_frame, smooth = misc.traj_error(X.copy(), Y.copy(), "golden", centered=centered)   # the function edits its inputs
+        tag = "c" if centered else "u"
+        aux[f"traj_mpjpe_{tag}"] = res.to_numpy(dtype=float).ravel()
+        aux[f"traj_frame_{tag}"] = np.asarray(per_frame, dtype=float)
+        aux[f"traj_smooth_{tag}"] = np.array(float(smooth))
+    np.savez(os.path.join(OUT, "contacts_metrics_golden.npz"), **aux)
+    with open(os.path.join(OUT, "contacts_metrics_lists.json"), "w") as f:
+        json.dump(lists, f, indent=1, sort_keys=True)
     names = dict(markers=misc.get_markers(), dlc_index=misc.get_dlc_marker_indices(), pairwise=misc.get_pairwise_graph())
     with open(os.path.join(OUT, "misc_names.json"), "w") as f:
         json.dump(names, f, indent=1, sort_keys=True)
