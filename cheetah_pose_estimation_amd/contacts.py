@@ -6,8 +6,9 @@ acinoset_misc.py:745-862 (contact_detection), :865-943 (synth_grf_data) and the 
 their index conventions, so that the files written here can be consumed where the reference's are.
 
 `pe.foot.Foot3D.ground_plane_height` lives in the un-vendored `physical_education` submodule; the ground is z = 0 in
-every stored reconstruction, which is the default used here (parity of that constant: unpinned).  The helper functions below
-are pinned by the outputs of the reference's own helpers (tests/golden/contacts_metrics_*, tools/gen_golden.py).
+every stored reconstruction, which is the default used here (parity of that constant: unpinned).  Everything else is pinned:
+tests/golden/contacts_metrics_* hold the outputs of the reference's own contact_detection, synth_grf_data and helpers on seeded
+series (tools/gen_golden.py), and tests/test_contacts.py compares this module with them.
 """
 import json
 import os

@@ -142,6 +142,54 @@ def main():
         aux[f"traj_mpjpe_{tag}"] = res.to_numpy(dtype=float).ravel()
         aux[f"traj_frame_{tag}"] = np.asarray(per_frame, dtype=float)
         aux[f"traj_smooth_{tag}"] = np.array(float(smooth))
+    # ---- the assembled contact rule and the force templates: contact_detection :745-862, synth_grf_data :865-943 ---------
+    # Both take the Pyomo robot.  Only its accessors are stood in for -- the four feet as plain objects holding a name and the
+    # foot-height series, `pe.foot.feet`, `pe.utils.get_vals` (returns the series), `pe.foot.Foot3D.ground_plane_height` = 0.0
+    # (the constant lives in the absent submodule), `init_foot_height` (no-op) and `init_foot_velocity` (returns the velocity
+    # series), and `DataFrame.to_hdf` (PyTables is absent: the frame is captured instead of written).  The decision logic that
+    # runs is the reference's own.
+    import tempfile
+    import pandas as pd
+    names = ["HFL_foot", "HFR_foot", "HBL_foot", "HBR_foot"]
+    pe = sys.modules["shared.physical_education"]
+    cases = []
+    for case, (N, fps, speed, start, touch) in enumerate(((60, 120.0, 12.0, 100, (10, 22, 34, 46)), (90, 120.0, 10.5, 0, (2, 40, 30, 85)),
+                                                          (70, 200.0, 9.0, 7, (15, 33, 51, 60)))):
+        n = np.arange(N)
+        z = 0.2 + 0.02 * np.sin(0.37 * n[:, None] + np.arange(4)[None, :]) + 0.003 * rng2.normal(size=(N, 4))
+        for i, c in enumerate(touch):
+            w = np.abs(n - c) <= 8
+            z[w, i] = 0.01 + 0.19 * ((n[w] - c) / 8.0) ** 2
+        if case == 1:                                       # a second contact of the first foot
+            w = np.abs(n - 70) <= 8
+            z[w, 0] = 0.012 + 0.19 * ((n[w] - 70) / 8.0) ** 2
+        vel = np.zeros((N, 4, 3))
+        vel[:, :, 2] = np.gradient(z, 1.0 / fps, axis=0)
+        feet = [types.SimpleNamespace(name=nm, pyomo_vars={"foot_height": z[:, i:i + 1].copy()}) for i, nm in enumerate(names)]
+        robot = types.SimpleNamespace(m=types.SimpleNamespace(fe=range(1, N + 1)))
+        pe.foot.feet = lambda r, feet=feet: feet
+        pe.foot.Foot3D = types.SimpleNamespace(ground_plane_height=0.0)
+        pe.utils.get_vals = lambda var, idx: var
+        misc.init_foot_height = lambda r: None
+        misc.init_foot_velocity = lambda r, vel=vel: vel
+        with tempfile.TemporaryDirectory() as tmp:
+            contacts, by_height = misc.contact_detection(robot, start, speed, fps, tmp, plot=False)
+            with open(os.path.join(tmp, "grf", "autogen-contact.json")) as f:
+                cj = json.load(f)
+            captured = {}
+            orig = pd.DataFrame.to_hdf
+            pd.DataFrame.to_hdf = lambda self, *a, **k: captured.setdefault("df", self.copy())
+            try:
+                direction = -1.0 if case != 1 else 1.0
+                misc.synth_grf_data(robot, speed, direction, os.path.join(tmp, "grf"))
+            finally:
+                pd.DataFrame.to_hdf = orig
+        df = captured["df"]
+        plates = {int(k): df.loc[k].to_numpy(dtype=float).tolist() for k in df.index.get_level_values(0).unique()}
+        aux[f"cd_height_{case}"], aux[f"cd_velz_{case}"] = z, vel[:, :, 2]
+        cases.append(dict(N=N, fps=fps, speed=speed, start_frame=start, direction=direction, contacts=contacts, by_height=by_height,
+                          json=cj, plates=plates))
+    lists["contact_cases"] = cases
     np.savez(os.path.join(OUT, "contacts_metrics_golden.npz"), **aux)
     with open(os.path.join(OUT, "contacts_metrics_lists.json"), "w") as f:
         json.dump(lists, f, indent=1, sort_keys=True)
