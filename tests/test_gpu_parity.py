@@ -142,6 +142,42 @@ def test_randomised_solve_parity_sweep(sk25, cams6, oracle, gpu_handle_factory):
     assert same_its >= B - 3 and worst < 1e-8
 
 
+def _kinetic_setup():
+    """the kinetic-dataset configuration of the reference (acinoset_misc.py:159-163, 187-188, 462-464; cheetah.py:306-352): four
+    pinhole cameras with radial distortion and objective multipliers [1, 1, .6, .6], sigma 7 px for every marker, the tighter
+    angle bounds of the `-02` models"""
+    sk = skeleton.build_skeleton("arabia-02", 24, kinetic_dataset=True)
+    cams = (abi.Camera * 4)()
+    for c, (x, y, z) in enumerate(((4.0, -6.0, 1.0), (9.0, -6.5, 1.2), (5.0, 6.0, 0.9), (10.0, 6.5, 1.1))):
+        cams[c] = synth.look_at_camera([x, y, z], [7.0, 0.0, 0.5], 1400.0 + 20 * c, 1390.0 - 10 * c, 960.0 + 5 * c, 540.0 - 3 * c,
+                                       [-0.08 + 0.01 * c, 0.02, -0.003, 0.0], model=abi.CAM_PINHOLE, mult=(1.0, 1.0, 0.6, 0.6)[c])
+    return sk, cams
+
+
+def test_kinetic_dataset_configuration_matches_oracle(oracle, gpu_handle_factory):
+    sk, cams = _kinetic_setup()
+    opts = abi.default_options(200.0)
+    h = gpu_handle_factory(sk, cams, opts)
+    d = synth.make_batch(sk, cams, B=3, N=30, fps=200.0, seed=41, kinetic_dataset=True)
+    assert (d["weight"] > 0).mean() > 0.2                                      # the animal is in view of the narrow cameras
+    q = d["q_true"] + np.random.default_rng(3).normal(0, 0.03, d["q_true"].shape)
+    r, J, eps, cost = h.eval_resjac_host(q, d["meas"], d["weight"])
+    sm, sd = h.jacobian_layout()
+    for b in range(3):
+        ro, Jo, eo, co = oracle.eval_resjac(sk, cams, opts, q[b], d["meas"][b], d["weight"][b])
+        assert np.abs(r[b] - ro).max() < 1e-8 * max(1.0, np.abs(ro).max())
+        assert np.abs(_dense_from_slots(J[b], sm, sd, 24, sk.nq) - Jo).max() < 1e-9 * np.abs(Jo).max()
+        assert np.abs(cost[b] - co).max() < 1e-9 * max(1.0, np.abs(co).max())       # includes the 0.6 multipliers of cameras 3, 4
+    out = h.solve_host(d["q_init"], d["meas"], d["weight"])
+    for b in range(3):
+        ref = oracle.solve(sk, cams, opts, None, d["q_init"][b], d["meas"][b], d["weight"][b])
+        st = out["stats"][b]
+        assert st.status == ref["stats"].status
+        assert abs(st.iterations - ref["stats"].iterations) <= 2 and st.outer == ref["stats"].outer
+        assert np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-5
+        assert abs(st.cost - ref["stats"].cost) < 1e-6 * abs(ref["stats"].cost)
+
+
 def test_solve_with_active_angle_bounds(sk25, cams6, oracle, gpu_handle_factory):
     """seed 31 / N=24 ends with an ACTIVE angle bound (cheetah.py:306-352): the augmented-Lagrangian
     multiplier updates must run on the GPU exactly as in the oracle."""
