@@ -39,6 +39,27 @@ def test_resjac_matches_oracle(L, cams6, oracle, gpu_handle_factory):
         assert np.abs(cost[b] - co).max() < 1e-9 * np.abs(co).max()
 
 
+@pytest.mark.parametrize("animal", ["jules", "acinoset", "shiraz-02"])
+def test_other_animals(animal, cams6, oracle, gpu_handle_factory):
+    """the other link tables of cheetah_params.py (SURVEY 8d cfg 5: four skeletons): FK, residual, Jacobian and a short solve"""
+    sk = skeleton.build_skeleton(animal, 24, kinetic_dataset=animal.endswith("-02"))
+    opts = abi.default_options()
+    h = gpu_handle_factory(sk, cams6, opts)
+    d = synth.make_batch(sk, cams6, B=2, N=12, seed=9)
+    r, J, eps, cost = h.eval_resjac_host(d["q_true"], d["meas"], d["weight"])
+    sm, sd = h.jacobian_layout()
+    for b in range(2):
+        ro, Jo, eo, co = oracle.eval_resjac(sk, cams6, opts, d["q_true"][b], d["meas"][b], d["weight"][b])
+        assert np.abs(r[b] - ro).max() < 1e-8 * max(1.0, np.abs(ro).max())
+        assert np.abs(_dense_from_slots(J[b], sm, sd, 24, sk.nq) - Jo).max() < 1e-9 * np.abs(Jo).max()
+    out = h.solve_host(d["q_init"], d["meas"], d["weight"])
+    for b in range(2):
+        ref = oracle.solve(sk, cams6, opts, None, d["q_init"][b], d["meas"][b], d["weight"][b])
+        assert out["stats"][b].status == ref["stats"].status
+        assert np.abs(out["positions"][b] - oracle.markers(sk, out["q"][b])).max() < 1e-12
+        assert np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-5
+
+
 def test_structural_zeros(sk25, cams6, oracle):
     """the slot layout covers every non-zero of the dense Jacobian (oracle side, no GPU needed for the
     claim but kept beside the GPU test that relies on it)"""
