@@ -218,20 +218,28 @@ __global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevM
         wave_lds_sync();
         for (int t = lane; t < 4 * nl; t += WAVE) rot_kind(ssc + 6 * (t >> 2), t & 3, sR + 9 * t);
         wave_lds_sync();
-        // marker positions from the LDS chain table
-        if (lane < L) {
-            double p0 = sq[0], p1 = sq[1], p2 = sq[2];
-            const int n = sclen[lane];
-            const int KL = L * CPE_MAX_CHAIN;
-            for (int k = 0; k < n; k++) {
-                const int t = k * L + lane;
-                const double v0 = chv[t], v1 = chv[KL + t], v2 = chv[2 * KL + t];
-                const double* R = sR + chr[t];
-                p0 += R[0] * v0 + R[1] * v1 + R[2] * v2;
-                p1 += R[3] * v0 + R[4] * v1 + R[5] * v2;
-                p2 += R[6] * v0 + R[7] * v1 + R[8] * v2;
+        // marker positions from the LDS chain table.  Two lanes per marker (2 L <= 64): lane l takes the even chain elements
+        // (and the base position), lane L + l the odd ones; the halves meet through one cross-lane read.  Halves the depth of
+        // the dependent table-index -> rotation reads.
+        {
+            const int half = lane >= L ? 1 : 0, l = lane - half * L;
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+            if (lane < 2 * L) {
+                if (!half) { p0 = sq[0]; p1 = sq[1]; p2 = sq[2]; }
+                const int n = sclen[l];
+                const int KL = L * CPE_MAX_CHAIN;
+                for (int k = half; k < n; k += 2) {
+                    const int t = k * L + l;
+                    const double v0 = chv[t], v1 = chv[KL + t], v2 = chv[2 * KL + t];
+                    const double* R = sR + chr[t];
+                    p0 += R[0] * v0 + R[1] * v1 + R[2] * v2;
+                    p1 += R[3] * v0 + R[4] * v1 + R[5] * v2;
+                    p2 += R[6] * v0 + R[7] * v1 + R[8] * v2;
+                }
             }
-            spos[3 * lane] = p0; spos[3 * lane + 1] = p1; spos[3 * lane + 2] = p2;
+            const int partner = (lane + L) & (WAVE - 1);
+            const double o0 = __shfl(p0, partner, WAVE), o1 = __shfl(p1, partner, WAVE), o2 = __shfl(p2, partner, WAVE);
+            if (lane < L) { spos[3 * lane] = p0 + o0; spos[3 * lane + 1] = p1 + o1; spos[3 * lane + 2] = p2 + o2; }
         }
         // d p / d q of my Jacobian slots (slot s = lane + 64 i) stay in registers
         double dp0[5], dp1[5], dp2[5];
