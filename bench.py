@@ -2,17 +2,22 @@
 """bench.py -- BASELINE.json's metric on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload = "cfg2"): synthetic 200-frame x 6-camera x 25-marker sequences,
-phantom skeleton, fp64.  One "step" = one pass of the residual+Jacobian hot path (k_resjac) over a batch of
-B sequences resident in HBM.  `value` = frames/s of that pass over all ranks; full-trajectory solves/s
-(cpe_solve, LM + block-banded Cholesky) are timed next to it and reported in "solves".
-Sequences are independent: ranks shard them, there is no collective on the data path (weak scaling).
+N > 1 works both ways: started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment), or started plainly as `python bench.py --gpus N`, in which case THIS process starts the N ranks
+as child processes before anything here has touched the GPU, waits for them and exits with their status.
+
+Workload (config.workload = "cfg2"): synthetic 200-frame x 6-camera x 25-marker sequences, phantom skeleton, fp64.
+One "step" = one pass of the residual+Jacobian hot path (k_resjac) over a batch of B sequences resident in HBM.  `value` =
+frames/s of that pass over all ranks; full-trajectory solves/s (cpe_solve: LM + block-banded Cholesky) are timed next to it and
+reported in "solves" with their own roofline object.  Sequences are independent: the global list of sequences is dealt to the
+ranks round-robin (cheetah_pose_estimation_amd.sharding), there is no collective on the data path (weak scaling).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,8 +26,38 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-BYTES_PER_FRAME = {25: 33360, 24: 32544}      # SURVEY 8d algorithmic bytes, C=6
 HBM_PEAK = 8.0e12
+FP64_PEAK = 78.6e12     # MI355X vector fp64 = matrix fp64 (no MFMA advantage for fp64 on gfx950)
+
+
+def resjac_bytes_per_frame(C, L, S, nq, with_cost):
+    """ALGORITHMIC bytes of one frame of k_resjac: read q, meas (and weight only when the robust cost is asked for --
+    k_resjac<false> never loads it); write residual, the S structurally non-zero Jacobian slots x 2 rows x C cameras, the
+    acceleration slack (and the cost).  C=6, L=25, S=276: 32 160 B without cost, 33 368 B with."""
+    b = 8 * nq + 16 * C * L + 16 * C * L + 16 * C * S + 8 * nq
+    return b + (8 * C * L + 8 if with_cost else 0)
+
+
+def solve_bytes_per_frame_iteration(C, L, nq=54, nu=28, nrev=12, pb=3):
+    """ALGORITHMIC bytes one LM iteration moves per frame: k_frame_normal reads the state (nq + nrev), meas, weight and
+    writes B (nu^2), g, Gamma (4 nrev), the cost record (8) and the consistent Euler angles; k_lm_step reads B, g, Gamma, the state
+    and the cost record, writes the factor column ((pb+1) nu^2), z and the total gradient, reads the factor column and z back in the
+    backward pass, writes delta, reads gradient + delta + diag(B) for the predicted reduction, and reads + writes the state for the
+    trial iterate."""
+    ns = nq + nrev
+    fn = 8 * (ns + 2 * C * L + C * L + nu * nu + nu + 4 * nrev + 8 + nq)
+    lm = 8 * (nu * nu + nu + 4 * nrev + ns + 8 + (pb + 1) * nu * nu + 2 * nu + (pb + 1) * nu * nu + nu + nu + 3 * nu + 2 * ns)
+    return fn, lm
+
+
+def lm_flops_per_frame_iteration(nu=28, pb=3):
+    """fp64 flops of k_lm_step per frame: Cholesky of the diagonal block, panel solve of pb blocks, trailing update of the window
+    (lower triangle of the pb diagonal blocks, all of the pb (pb-1)/2 others), right-hand side, backward substitution"""
+    chol = nu ** 3 / 3.0
+    panel = pb * nu * nu * nu
+    trail = pb * nu * (nu + 1) * nu + (pb * (pb - 1) // 2) * 2 * nu ** 3
+    rhs = 2 * pb * nu * nu + 2 * (pb + 1) * nu * nu
+    return chol + panel + trail + rhs
 
 
 def tile_batch(torch, d, B, dev, seed):
@@ -37,12 +72,41 @@ def tile_batch(torch, d, B, dev, seed):
         out[k] = t.repeat((reps,) + (1,) * (t.dim() - 1))[:B].contiguous()
     out["q_true"] += 1e-3 * torch.randn(out["q_true"].shape, generator=g, device=dev, dtype=torch.float64)
     out["q_init"][..., :3] += 1e-3 * torch.randn(out["q_init"][..., :3].shape, generator=g, device=dev, dtype=torch.float64)
+    torch.cuda.synchronize(dev)            # the handle launches on its own stream: nothing of the above may still be in flight
     return out
 
 
+def usable_cores():
+    """(cores this process can really run on, how that was found): the scheduler affinity, capped by the cgroup CPU quota when the
+    container has one (a one-GPU box shows 256 host threads in its affinity mask but gives the job a 16-core quota; 256 OpenMP
+    threads on 16 cores measured 2.4x SLOWER than 16)."""
+    n = len(os.sched_getaffinity(0))
+    how = f"sched_getaffinity={n}"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:            # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            q = max(1, int(round(int(quota) / int(period))))
+            how += f", cgroup cpu.max={q}"
+            n = min(n, q)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                quota = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                period = int(fh.read())
+            if quota > 0:
+                q = max(1, int(round(quota / period)))
+                how += f", cgroup cfs_quota={q}"
+                n = min(n, q)
+        except Exception:
+            pass
+    return n, how
+
+
 def cpu_baseline(sk, cams, opts, d, budget_s=8.0):
-    """CPU oracle (oracle/, plain C) timed on a bounded sample of the same workload: one thread (the scalar port) and
-    OpenMP over sequences on this box's CPU share; the same C loop for both, output buffers reused across sequences."""
+    """CPU oracle (oracle/, plain C) timed on a bounded sample of the same workload: one thread (the scalar port) and OpenMP over
+    sequences on every host core this process may run on (count stated); the same C code for both."""
     from oracle import oracle as O
     O.lib()
     Bq, N = d["q_true"].shape[0], d["q_true"].shape[1]
@@ -57,15 +121,32 @@ def cpu_baseline(sk, cams, opts, d, budget_s=8.0):
 
     _, _, _, probe = timed(1, 0.0, 1.0)                     # one pass: calibrates the sample size
     u1, n1, dt1, rate1 = timed(1, budget_s, probe)
-    share = min(len(os.sched_getaffinity(0)), 16)           # a one-GPU box gives a job 16 host cores
-    um, nm, dtm, ratem = timed(share, 0.5 * budget_s, rate1 * share)
+    cores, how = usable_cores()                             # every core this process may use (affinity, cgroup quota if readable)
+    # a quota the files above do not show (the one-GPU boxes: 256 threads in the mask, 16 cores' worth of time) would make `cores`
+    # threads thrash: probe a few thread counts for ~0.3 s each and keep the fastest
+    best = (0.0, 1)
+    for tc in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256)} | {cores}):
+        _, _, _, r_tc = timed(tc, 0.3, rate1 * min(tc, 16))
+        if r_tc > best[0]:
+            best = (r_tc, tc)
+    how += f", fastest of the probed thread counts: {best[1]}"
+    cores = best[1]
+    um, nm, dtm, ratem = timed(cores, 0.5 * budget_s, best[0])
     t1 = time.perf_counter()
     res = O.solve(sk, cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
     ts = time.perf_counter() - t1
+    # multi-thread solves: one sequence per thread at a time, as many rounds as fit in half the budget (at least one)
+    nb = cores * max(1, int(0.5 * budget_s / max(ts, 1e-3)))
+    rep = (nb + Bq - 1) // Bq
+    qi = np.tile(d["q_init"], (rep, 1, 1))[:nb]; me = np.tile(d["meas"], (rep, 1, 1, 1, 1))[:nb]; we = np.tile(d["weight"], (rep, 1, 1, 1))[:nb]
+    t2 = time.perf_counter()
+    us, _, its = O.solve_batch(sk, cams, opts, qi, me, we, threads=cores)
+    tm = time.perf_counter() - t2
     return dict(value=rate1, unit="frames/s", cores=1, kind="port",
                 sample=f"{n1} sequences x {N} frames of the same synthetic workload, oracle/cpe_oracle.c single thread, {dt1:.1f} s",
-                solves_per_s=1.0 / ts, solve_iterations=int(res["stats"].iterations), host_cores_available=os.cpu_count(),
-                multi_thread=dict(value=ratem, unit="frames/s", cores=um, sample=f"{nm} sequences, OpenMP over sequences, {dtm:.1f} s"))
+                solves_per_s=1.0 / ts, solve_iterations=int(res["stats"].iterations), host_cores_available=os.cpu_count(), cores_usable=how,
+                multi_thread=dict(value=ratem, unit="frames/s", cores=um, sample=f"{nm} sequences, OpenMP over sequences, {dtm:.1f} s",
+                                  solves_per_s=nb / tm, solve_sample=f"{nb} sequences on {us} threads, {tm:.1f} s, {float(its.mean()):.1f} iterations on average"))
 
 
 def pmc_traffic(B, N, C, L):
@@ -86,6 +167,22 @@ def pmc_traffic(B, N, C, L):
     return best
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent never imports torch
+    or touches the GPU), one per GPU, rendezvous on 127.0.0.1; rank 0 prints the JSON line.  Returns the worst exit status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,15 +197,35 @@ def main():
     ap.add_argument("--no-l24", action="store_true", help="skip the extra 24-marker residual+Jacobian measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                    # nothing above this line has initialised the GPU
+
     import torch
     import torch.distributed as dist
-    from cheetah_pose_estimation_amd import _lib, abi, skeleton, synth
+    from cheetah_pose_estimation_amd import _lib, abi, sharding, skeleton, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    # CPE_BENCH_REHEARSAL=1: rehearse the multi-rank path on a ONE-GPU box -- every rank uses cuda:0 and the two collectives
+    if os.environ.get("CPE_BENCH_DRYRUN") == "1":
+        # CPU rehearsal of the launch plumbing only (tests/test_bench_contract.py): rendezvous over gloo, the dealing of the
+        # sequences, the barrier, the MAX over ranks and rank 0's single JSON line -- no GPU, no kernels, no numbers
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+        mine = sharding.shard_indices(world * 4, rank, world)
+        owned = sharding.gather_by_index([int(i) for i in mine], world * 4, rank, world)
+        tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "owned": owned, "max_over_ranks": float(tmax.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    # CPE_BENCH_REHEARSAL=1: rehearse the multi-rank path on a box with fewer GPUs -- every rank uses cuda:0 and the two collectives
     # (timing barrier, MAX over ranks) go over gloo.  The numbers of such a run mean nothing; it checks the plumbing.
     rehearsal = os.environ.get("CPE_BENCH_REHEARSAL") == "1"
     if rehearsal:
@@ -136,12 +253,16 @@ def main():
     h = _lib.Handle(sk, cams, opts, device=local)
     S = h.S
     P = 32
-    d = synth.make_batch(sk, cams, B=P, N=N, seed=1234 + 1000 * rank)     # sequence b uses seed 1234 + b (+ rank offset)
+    # the global list of unique sequences (seed 1234 + index) is dealt to the ranks round-robin: no two ranks own the same one
+    mine = sharding.shard_indices(world * P, rank, world)
+    parts = [synth.make_batch(sk, cams, B=1, N=N, seed=1234 + i) for i in mine]
+    d = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
     B = args.batch
     t = tile_batch(torch, d, B, dev, seed=rank)
     r = torch.empty((B, N, C, L, 2), dtype=torch.float64, device=dev)
     J = torch.empty((B, N, C, S, 2), dtype=torch.float64, device=dev)
     eps = torch.empty((B, N, sk.nq), dtype=torch.float64, device=dev)
+    cost = torch.empty((B, N), dtype=torch.float64, device=dev)
     stream = torch.cuda.ExternalStream(h.stream, device=dev)               # events on the stream the kernels run on
 
     def barrier():
@@ -149,6 +270,15 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def time_resjac(hh, tt, rr, JJ, ee, cc, n, st):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record(st)
+            hh.eval_resjac(tt["q_true"], tt["meas"], tt["weight"], rr, JJ, ee, cc)
+            b.record(st)
+        hh.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     for _ in range(args.warmup):
         h.eval_resjac(t["q_true"], t["meas"], t["weight"], r, J, eps, None)
@@ -167,6 +297,8 @@ def main():
     elapsed = max_over_ranks(elapsed)
     frames_total = world * B * N * args.steps
     value = frames_total / elapsed
+    # the variant that also reads the weights and writes the robust cost (k_resjac<true>), for the record
+    ms_cost = time_resjac(h, t, r, J, eps, cost, 5, stream) if world == 1 else None
 
     # "also report L=24" -- the reference's own 24 markers, same cameras and sequence shape, same kernel
     l24 = None
@@ -183,15 +315,9 @@ def main():
         for _ in range(max(2, args.warmup)):
             h24.eval_resjac(t24["q_true"], t24["meas"], t24["weight"], r, J, eps, None)
         h24.synchronize()
-        e24 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-        for a, b in e24:
-            a.record(s24)
-            h24.eval_resjac(t24["q_true"], t24["meas"], t24["weight"], r, J, eps, None)
-            b.record(s24)
-        h24.synchronize()
-        ms24 = float(np.mean([a.elapsed_time(b) for a, b in e24]))
-        l24 = dict(value=B * N / (ms24 * 1e-3), unit="frames/s", kernel_ms=ms24, bytes_per_frame=BYTES_PER_FRAME[24],
-                   frac=BYTES_PER_FRAME[24] * B * N / (ms24 * 1e-3) / HBM_PEAK)
+        ms24 = time_resjac(h24, t24, r, J, eps, None, 5, s24)
+        b24 = resjac_bytes_per_frame(C, 24, h24.S, sk24.nq, False)
+        l24 = dict(value=B * N / (ms24 * 1e-3), unit="frames/s", kernel_ms=ms24, bytes_per_frame=b24, frac=b24 * B * N / (ms24 * 1e-3) / HBM_PEAK)
         h24.close()
         del t24
 
@@ -199,10 +325,15 @@ def main():
     if not args.no_solve:
         Bs = args.solve_batch
         ts_ = tile_batch(torch, d, Bs, dev, seed=100 + rank)
-        r = J = eps = None
+        r = J = eps = cost = None
         q = torch.empty((Bs, N, sk.nq), dtype=torch.float64, device=dev); dq = torch.empty_like(q); ddq = torch.empty_like(q)
         pos = torch.empty((Bs, N, L, 3), dtype=torch.float64, device=dev); me = torch.empty((Bs, N, C, L, 2), dtype=torch.float64, device=dev)
-        h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)   # warm-up at full size: the solver workspace (16 GB for 2048 sequences) is allocated here
+        # warm-up at full size (the solver workspace, 16 GB for 2048 sequences, is allocated here), with the per-kernel HIP-event
+        # profile switched on: this untimed run supplies the kernel times of the roofline object
+        h.profile(True)
+        _, wstats = h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)
+        prof = h.profile_totals()
+        h.profile(False)
         barrier()
         t1 = time.perf_counter()
         st, stats = h.solve(ts_["q_init"], ts_["meas"], ts_["weight"], q, dq, ddq, pos, me)
@@ -211,11 +342,46 @@ def main():
         el = max_over_ranks(el)
         its = np.array([s.iterations for s in stats])
         stt = np.array([s.status for s in stats])
+        # every LM iteration of a sequence evaluates and factors all its N frames (+1: the first evaluation)
+        frame_its = float((its + 1).sum()) * N
+        fn_b, lm_b = solve_bytes_per_frame_iteration(C, L, sk.nq, h.nu, 12, 3)
+        lm_ms, lm_n = prof.get("k_lm_step", (0.0, 0))
+        fn_ms, fn_n = prof.get("k_frame_normal", (0.0, 0))
+        wframe_its = float((np.array([s.iterations for s in wstats]) + 1).sum()) * N
+        roof = {"bound": "hbm", "kernel": "k_lm_step<3>", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+                "achieved": (lm_b * wframe_its / (lm_ms * 1e-3) / 1e9) if lm_ms else None,
+                "frac": (lm_b * wframe_its / (lm_ms * 1e-3) / HBM_PEAK) if lm_ms else None, "traffic": None,
+                "bytes_per_frame_iteration": lm_b, "kernel_ms_total": lm_ms, "launches": lm_n,
+                "fp64": {"achieved_tflops": (lm_flops_per_frame_iteration() * wframe_its / (lm_ms * 1e-3) / 1e12) if lm_ms else None,
+                         "peak_tflops": FP64_PEAK / 1e12,
+                         "frac": (lm_flops_per_frame_iteration() * wframe_its / (lm_ms * 1e-3) / FP64_PEAK) if lm_ms else None},
+                "k_frame_normal": {"bytes_per_frame_iteration": fn_b, "kernel_ms_total": fn_ms, "launches": fn_n,
+                                   "frac": (fn_b * wframe_its / (fn_ms * 1e-3) / HBM_PEAK) if fn_ms else None},
+                "whole_solve": {"bytes_per_frame_iteration": fn_b + lm_b, "achieved": (fn_b + lm_b) * frame_its / el / 1e9,
+                                "frac": (fn_b + lm_b) * frame_its / el / HBM_PEAK},
+                "note": "latency-bound (200 sequential block columns x 28 pivots per sequence): far from both rooflines, see DESIGN.md 6"}
         solves = dict(value=world * Bs / el, unit="solves/s", batch_per_gpu=Bs, seconds=el, iterations_mean=float(its.mean()),
-                      iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()))
+                      iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()), roofline=roof)
+        if world == 1:
+            # latency of ONE sequence through the drop-in path's solver (B = 1: one workgroup on one CU), N = 200 and N = 57
+            lat = {}
+            for n1 in (N, 57):
+                d1 = synth.make_batch(sk, cams, B=1, N=n1, seed=1234)
+                t1_ = {k: torch.tensor(v, device=dev) for k, v in d1.items()}
+                o = [torch.empty((1, n1, sk.nq), dtype=torch.float64, device=dev) for _ in range(3)]
+                p1 = torch.empty((1, n1, L, 3), dtype=torch.float64, device=dev); m1 = torch.empty((1, n1, C, L, 2), dtype=torch.float64, device=dev)
+                torch.cuda.synchronize(dev)
+                times = []
+                for _ in range(4):
+                    ta = time.perf_counter()
+                    _, s1 = h.solve(t1_["q_init"], t1_["meas"], t1_["weight"], o[0], o[1], o[2], p1, m1)
+                    h.synchronize()
+                    times.append(time.perf_counter() - ta)
+                lat[f"N{n1}"] = dict(ms=1e3 * float(np.median(times[1:])), iterations=int(s1[0].iterations), status=int(s1[0].status))
+            solves["latency_b1"] = lat
 
     if rank == 0:
-        bpf = BYTES_PER_FRAME.get(L, 33360)
+        bpf = resjac_bytes_per_frame(C, L, S, sk.nq, False)
         ach = bpf * B * N / (kern_ms * 1e-3)
         out = {
             "metric": "frames/sec residual+Jacobian eval + full-traj solves/sec, 200-frame 6-cam seq",
@@ -228,9 +394,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                          "traffic": pmc_traffic(B, N, C, L), "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
         }
+        if ms_cost is not None:
+            bc = resjac_bytes_per_frame(C, L, S, sk.nq, True)
+            out["with_cost"] = {"kernel": "k_resjac<true>", "kernel_ms": ms_cost, "bytes_per_frame": bc, "value": B * N / (ms_cost * 1e-3),
+                                "frac": bc * B * N / (ms_cost * 1e-3) / HBM_PEAK}
         if not args.no_cpu and world == 1:          # the CPU leg is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(sk, cams, opts, d)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     h.close()
     if world > 1:
         dist.destroy_process_group()

@@ -58,6 +58,10 @@ def load():
                                C.POINTER(abi.Priors), C.c_int32, C.POINTER(C.c_void_p)]
     lib.cpe_destroy.argtypes = [C.c_void_p]
     lib.cpe_synchronize.argtypes = [C.c_void_p]
+    lib.cpe_stream_wait.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cpe_stream_signal.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cpe_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+    lib.cpe_profile_get.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64)]
     lib.cpe_jacobian_slots.argtypes = [C.c_void_p]
     lib.cpe_jacobian_layout.argtypes = [C.c_void_p, ip, ip]
     lib.cpe_num_independent.argtypes = [C.c_void_p]
@@ -135,6 +139,30 @@ class Handle:
     def synchronize(self):
         _check(self.lib.cpe_synchronize(self._h), "cpe_synchronize")
 
+    # The device-pointer entry points enqueue on the handle's own stream (include/cpe.h, "Synchronisation contract").  Torch
+    # tensors are produced and consumed on torch's current stream, so every device-pointer method below brackets its call:
+    # the handle first waits for what torch has queued, and torch's stream afterwards waits for what the handle has queued.
+    def _torch_stream(self):
+        import torch
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _enter(self):
+        _check(self.lib.cpe_stream_wait(self._h, self._torch_stream()), "cpe_stream_wait")
+
+    def _leave(self):
+        _check(self.lib.cpe_stream_signal(self._h, self._torch_stream()), "cpe_stream_signal")
+
+    PROFILE_SLOTS = ("k_frame_normal", "k_lr_band", "k_lm_step", "k_build_act", "k_finalize", "k_dyn_term", "k_dyn_gather", "other")
+
+    def profile(self, on: bool):
+        _check(self.lib.cpe_profile_enable(self._h, 1 if on else 0), "cpe_profile_enable")
+
+    def profile_totals(self):
+        """{kernel: (milliseconds, launches)} accumulated by the solves since profile(True)"""
+        ms = (C.c_double * 8)(); n = (C.c_int64 * 8)()
+        _check(self.lib.cpe_profile_get(self._h, ms, n), "cpe_profile_get")
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(self.PROFILE_SLOTS) if n[i]}
+
     def jacobian_layout(self):
         sm = np.empty(self.S, dtype=np.int32); sd = np.empty(self.S, dtype=np.int32)
         _check(self.lib.cpe_jacobian_layout(self._h, sm.ctypes.data_as(ip), sd.ctypes.data_as(ip)), "cpe_jacobian_layout")
@@ -148,25 +176,36 @@ class Handle:
     # ---- device-pointer entry points (torch-ROCm tensors on self.device) -------------------------------
     def eval_resjac(self, q, meas, weight, r, J, eps, cost=None):
         B, N = q.shape[0], q.shape[1]
+        self._enter()
         _check(self.lib.cpe_eval_resjac(self._h, B, N, _ptr(q), _ptr(meas), _ptr(weight), _ptr(r), _ptr(J), _ptr(eps), _ptr(cost)),
                "cpe_eval_resjac")
+        self._leave()
 
     def project_joints(self, q):
-        return _check(self.lib.cpe_project_joints(self._h, q.shape[0], q.shape[1], _ptr(q)), "cpe_project_joints",
-                      allow=(abi.OK, abi.NUMERICAL))
+        self._enter()
+        st = _check(self.lib.cpe_project_joints(self._h, q.shape[0], q.shape[1], _ptr(q)), "cpe_project_joints",
+                    allow=(abi.OK, abi.NUMERICAL))
+        self._leave()
+        return st
 
     def forward_kinematics(self, q, positions, com=None):
+        self._enter()
         _check(self.lib.cpe_forward_kinematics(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(positions), _ptr(com)),
                "cpe_forward_kinematics")
+        self._leave()
 
     def marker_velocities(self, q, dq, velocities):
         """v_l = (d p_l / d q) dq for every marker (device tensors; velocities [B, N, L, 3])"""
+        self._enter()
         _check(self.lib.cpe_marker_velocities(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(velocities)),
                "cpe_marker_velocities")
+        self._leave()
 
     def reproject(self, positions, uv):
         """stored 3D markers -> pixels in every camera (device tensors; uv [B, N, C, L, 2])"""
+        self._enter()
         _check(self.lib.cpe_reproject(self._h, positions.shape[0], positions.shape[1], _ptr(positions), _ptr(uv)), "cpe_reproject")
+        self._leave()
 
     def reproject_host(self, positions):
         """numpy [B, N, L, 3] -> numpy [B, N, C, L, 2] (staged through HBM with torch)"""
@@ -190,6 +229,7 @@ class Handle:
         if not (cb.shape[0] == n and ua.shape[0] == n and ub.shape[0] == n):
             raise CpeError("triangulate_host: array lengths differ")
         xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        self._enter()
         _check(self.lib.cpe_triangulate(self._h, n, _ptr(ca), _ptr(cb), _ptr(ua), _ptr(ub), float(depth), _ptr(xyz)), "cpe_triangulate")
         self.synchronize()
         return xyz.cpu().numpy()
@@ -209,6 +249,7 @@ class Handle:
             t = torch.tensor(np.ascontiguousarray(tab, dtype=np.float64), device=dev)
             if t.dim() != 2 or t.shape[1] % 3:
                 raise CpeError("tensorise_dlc_host: a DLC table has 3 columns per body part")
+            self._enter()
             _check(self.lib.cpe_tensorise_dlc(self._h, N, Cn, c, _ptr(t), int(t.shape[0]), int(t.shape[1] // 3), int(first_rows[c]), _ptr(pm), _ptr(isg),
                                               float(thresh), _ptr(meas), _ptr(weight)), "cpe_tensorise_dlc")
             self.synchronize()                      # `t` must outlive the launch
@@ -228,30 +269,40 @@ class Handle:
         return pos.cpu().numpy(), vel.cpu().numpy()
 
     def eval_normal(self, q, meas, weight, g, Bm, cost, gam=None, q_out=None):
+        self._enter()
         _check(self.lib.cpe_eval_normal(self._h, q.shape[0], q.shape[1], _ptr(q), _ptr(meas), _ptr(weight), _ptr(g), _ptr(Bm), _ptr(cost),
                                         _ptr(gam), _ptr(q_out)), "cpe_eval_normal")
+        self._leave()
 
     def solve(self, q_init, meas, weight, q, dq, ddq, positions, meas_err):
         B, N = q_init.shape[0], q_init.shape[1]
         stats = (abi.Stats * max(B, 1))()
+        self._enter()
         st = self.lib.cpe_solve(self._h, B, N, _ptr(q_init), _ptr(meas), _ptr(weight), _ptr(q), _ptr(dq), _ptr(ddq),
                                 _ptr(positions), _ptr(meas_err), stats)
+        self._leave()
         _check(st, "cpe_solve", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
         return st, list(stats)[:B]
 
     def eom_rows(self, eopt, q, dq, ddq, rows):
         """all rows of d/dt dL/dq' - dL/dq (device tensors [B, N, nq])"""
+        self._enter()
         _check(self.lib.cpe_eom_rows(self._h, C.byref(eopt), q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(ddq), _ptr(rows)), "cpe_eom_rows")
+        self._leave()
 
     def eom_residual(self, dopt, q, dq, ddq, tau, lam, grf, residual):
         """rows of the equations of motion minus the generalised forces (device tensors; tau / lam / grf may be None)"""
+        self._enter()
         _check(self.lib.cpe_eom_residual(self._h, C.byref(dopt), q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(ddq), _ptr(tau), _ptr(lam),
                                          _ptr(grf), _ptr(residual)), "cpe_eom_residual")
+        self._leave()
 
     def grf_fit(self, gopt, q, dq, ddq, contact, grfz, grfxy, residual=None):
         """per-frame ground-reaction-force fit (device tensors); contact int32 [B, N, n_feet]"""
+        self._enter()
         _check(self.lib.cpe_grf_fit(self._h, C.byref(gopt), q.shape[0], q.shape[1], _ptr(q), _ptr(dq), _ptr(ddq), _ptr(contact),
                                     _ptr(grfz), _ptr(grfxy), _ptr(residual)), "cpe_grf_fit")
+        self._leave()
 
     def grf_fit_host(self, gopt, q, dq, ddq, contact):
         """numpy in, numpy out (staged through HBM with torch): grfz [B, N, nf], grfxy [B, N, nf, 4], residual [B, N, 6]"""

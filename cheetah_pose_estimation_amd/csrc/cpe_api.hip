@@ -33,7 +33,16 @@ struct cpe_handle {
            *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr, *gambuf = nullptr;
     SeqState* st = nullptr;
     int* flag = nullptr;
-    int* act = nullptr;          // [ws_B] sequences of the current launch window
+    int* act = nullptr;          // [ws_B] sequences of the current launch window (written by k_build_act)
+    int* n_act = nullptr;        // device word: entries of act in use
+    int* poll_host = nullptr;    // pinned host memory: two snapshots of n_act, read without draining the stream
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    hipEvent_t order_ev = nullptr;   // cpe_stream_wait / cpe_stream_signal
+    // per-kernel device time of the last cpe_solve (cpe_profile_enable / cpe_profile_get)
+    bool prof = false;
+    double prof_ms[CPE_PROFILE_SLOTS] = {0};
+    int64_t prof_n[CPE_PROFILE_SLOTS] = {0};
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_spans;
     cpe_eom_options* eom = nullptr;   // device copy of the last cpe_eom_rows options
     cpe_dyn_options* dyn = nullptr;   // device copy of the last cpe_eom_residual options
     // learned priors (config 3)
@@ -358,6 +367,10 @@ static cpe_status create_impl(cpe_handle* h, const cpe_skeleton* skel, const cpe
         for (const void* k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->poll_host), 2 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&h->n_act, sizeof(int)));
     HIPCHK(hipMalloc(&h->dm, sizeof(DevModel)));
     HIPCHK(hipMemcpy(h->dm, &h->hm, sizeof(DevModel), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&h->flag, sizeof(int)));
@@ -428,6 +441,11 @@ void cpe_destroy(cpe_handle* h) {
     if (h->pri) (void)hipFree(h->pri);
     if (h->eom) (void)hipFree(h->eom);
     if (h->dyn) (void)hipFree(h->dyn);
+    if (h->n_act) (void)hipFree(h->n_act);
+    if (h->poll_host) (void)hipHostFree(h->poll_host);
+    for (int i = 0; i < 2; i++) if (h->poll_ev[i]) (void)hipEventDestroy(h->poll_ev[i]);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
+    for (auto& sp : h->prof_spans) { (void)hipEventDestroy(sp.second.first); (void)hipEventDestroy(sp.second.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -437,6 +455,54 @@ cpe_status cpe_synchronize(cpe_handle* h) {
     if (!h) return fail(CPE_BAD_ARG, "null handle");
     HIPCHK(hipStreamSynchronize(h->stream));
     return CPE_OK;
+}
+
+// ---- ordering against the caller's stream (e.g. torch's current stream) ---------------------------------------------
+cpe_status cpe_stream_wait(cpe_handle* h, void* other) {
+    if (!h) return fail(CPE_BAD_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->order_ev, (hipStream_t)other));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->order_ev, 0));
+    return CPE_OK;
+}
+cpe_status cpe_stream_signal(cpe_handle* h, void* other) {
+    if (!h) return fail(CPE_BAD_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->order_ev, h->stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)other, h->order_ev, 0));
+    return CPE_OK;
+}
+
+// ---- per-kernel device time of cpe_solve ------------------------------------------------------------------------------
+cpe_status cpe_profile_enable(cpe_handle* h, int32_t on) {
+    if (!h) return fail(CPE_BAD_ARG, "null handle");
+    h->prof = on != 0;
+    for (int i = 0; i < CPE_PROFILE_SLOTS; i++) { h->prof_ms[i] = 0.0; h->prof_n[i] = 0; }
+    return CPE_OK;
+}
+cpe_status cpe_profile_get(cpe_handle* h, double* ms, int64_t* launches) {
+    if (!h || !ms || !launches) return fail(CPE_BAD_ARG, "null argument");
+    for (int i = 0; i < CPE_PROFILE_SLOTS; i++) { ms[i] = h->prof_ms[i]; launches[i] = h->prof_n[i]; }
+    return CPE_OK;
+}
+static void prof_begin(cpe_handle* h, int id) {
+    if (!h->prof) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(a, h->stream);
+    h->prof_spans.push_back({id, {a, b}});
+}
+static void prof_end(cpe_handle* h) {
+    if (!h->prof || h->prof_spans.empty()) return;
+    (void)hipEventRecord(h->prof_spans.back().second.second, h->stream);
+}
+static void prof_collect(cpe_handle* h) {       // after the stream has been synchronised
+    for (auto& sp : h->prof_spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.second.first, sp.second.second) == hipSuccess) { h->prof_ms[sp.first] += ms; h->prof_n[sp.first]++; }
+        (void)hipEventDestroy(sp.second.first); (void)hipEventDestroy(sp.second.second);
+    }
+    h->prof_spans.clear();
 }
 
 int32_t cpe_jacobian_slots(const cpe_handle* h) { return h ? h->hm.S : 0; }
@@ -656,7 +722,7 @@ cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q,
     HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
-                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr);
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr);
     HIPCHK(hipMemcpyAsync(g, h->gbuf, sizeof(double) * F * m.nu, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(Bm, h->Bbuf, sizeof(double) * F * m.nu * m.nu, hipMemcpyDeviceToDevice, h->stream));
     hipLaunchKernelGGL(k_gather_normal, dim3((unsigned)F), dim3(128), 0, h->stream, h->dm, F, h->qbuf, h->costbuf, h->gambuf, cost, gam, q_out);
@@ -685,55 +751,70 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;
     const size_t ldsn = lds_normal(m, h->gmm_k, h->gmm_dim);
     const bool lr = h->lr_window > 0;
-    // One LM iteration = k_frame_normal (+ k_lr_band) on the evaluated buffer, then k_lm_step, for the sequences listed in `act`
-    // (device int array, nullptr = all B).
-    auto iterate = [&](int first, const int* act, int n_act) {
-        const unsigned gf = (unsigned)((size_t)n_act * N);
+    // One LM iteration = k_frame_normal (+ k_lr_band) on the evaluated buffer, then k_lm_step, for the first *n_act sequences listed
+    // in `act` (device arrays; nullptr = all B).  The grids are sized for `slots` sequences; workgroups past *n_act leave at once.
+    auto iterate = [&](int first, const int* act, const int* n_act, int slots) {
+        const unsigned gf = (unsigned)((size_t)slots * N);
+        prof_begin(h, 0);
         hipLaunchKernelGGL(k_frame_normal, dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
-                           h->costbuf, h->mu, h->gambuf, h->pri, act);
-        if (lr) hipLaunchKernelGGL(k_lr_band, dim3(gf), dim3(WAVE), 0, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf,
-                                   h->Hlr, h->costbuf, act);
-        if (h->pb == 3) hipLaunchKernelGGL(k_lm_step<3>, dim3(n_act), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act);
-        else hipLaunchKernelGGL(k_lm_step<4>, dim3(n_act), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act);
+                           h->costbuf, h->mu, h->gambuf, h->pri, act, n_act);
+        prof_end(h);
+        if (lr) {
+            prof_begin(h, 1);
+            hipLaunchKernelGGL(k_lr_band, dim3(gf), dim3(WAVE), 0, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, h->gambuf, h->pri, h->pb, h->gbuf, h->Bbuf,
+                               h->Hlr, h->costbuf, act, n_act);
+            prof_end(h);
+        }
+        prof_begin(h, 2);
+        if (h->pb == 3) hipLaunchKernelGGL(k_lm_step<3>, dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
+                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act);
+        else hipLaunchKernelGGL(k_lm_step<4>, dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
+                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act);
+        prof_end(h);
     };
-    iterate(1, nullptr, B);                 // first evaluation and first step of every sequence
+    iterate(1, nullptr, nullptr, B);        // first evaluation and first step of every sequence
     HIPCHK(hipGetLastError());
     // Active window: k_lm_step runs one workgroup per sequence and its duration is the sequential depth of ONE sequence,
-    // whatever the grid (3.3 ms for <= 256 workgroups, 4.4 ms for 512 = 2 per CU), so the launches are kept exactly full: the first
-    // `window` unfinished sequences iterate, the list is rebuilt every POLL iterations from the status words, and a
-    // sequence that converges hands its slot to the next waiting one instead of idling until the slowest of its batch ends.
-    std::vector<SeqState> hs(B);
-    std::vector<int> act_h;
-    const int window = h->n_cu * (h->pb == 3 ? 2 : 1);
-    constexpr int POLL = 4;                 // small launches: poll every 4th iteration; large ones (>= 16k frames, several ms) every iteration
+    // whatever the grid (3.3 ms for <= 256 workgroups, 4.4 ms for 512 = 2 per CU), so the launches are kept exactly full: before
+    // every iteration k_build_act lists the first `window` unfinished sequences ON THE DEVICE, so a sequence that converges hands
+    // its slot to the next waiting one at once and the host never waits for an iteration: it queues POLL iterations, then reads
+    // the PREVIOUS batch's snapshot of the list length (pinned memory + event) -- the stream stays at least one batch ahead and
+    // is never drained inside the loop.  The price is at most 2 POLL iterations of empty launches after the last sequence ends.
+    const int window = std::min(B, h->n_cu * (h->pb == 3 ? 2 : 1));
+    constexpr int POLL = 4;
     const long per_seq = (long)h->opts.max_iter + 2L * (h->opts.max_outer > 0 ? h->opts.max_outer : 0) + POLL;
     const long max_rounds = ((long)(B + window - 1) / window + 1) * per_seq;
-    int n_act = 0;
-    long next_poll = 0;
-    for (long it = 0; it < max_rounds; it++) {
-        if (it >= next_poll) {
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            act_h.clear();
-            for (int b = 0; b < B && (int)act_h.size() < window; b++) if (hs[b].status == 0) act_h.push_back(b);
-            n_act = (int)act_h.size();
-            if (n_act == 0) break;
-            HIPCHK(hipMemcpyAsync(h->act, act_h.data(), sizeof(int) * n_act, hipMemcpyHostToDevice, h->stream));
-            next_poll = it + ((size_t)n_act * N >= 16384 ? 1 : POLL);
+    bool pending[2] = {false, false};
+    int slot = 0;
+    for (long it = 0; it < max_rounds; it += POLL) {
+        for (int k = 0; k < POLL; k++) {
+            prof_begin(h, 3);
+            hipLaunchKernelGGL(k_build_act, dim3(1), dim3(256), 0, h->stream, h->st, B, window, h->act, h->n_act);
+            prof_end(h);
+            iterate(0, h->act, h->n_act, window);
         }
-        iterate(0, h->act, n_act);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->poll_host + slot, h->n_act, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->poll_ev[slot], h->stream));
+        pending[slot] = true;
+        const int prev = 1 - slot;
+        if (pending[prev]) {
+            HIPCHK(hipEventSynchronize(h->poll_ev[prev]));
+            pending[prev] = false;
+            if (h->poll_host[prev] == 0) break;          // no sequence was running when that list was built
+        }
+        slot = prev;
     }
     HIPCHK(hipMemsetAsync(h->cmax, 0, sizeof(double) * B, h->stream));
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, Fw, h->qbuf, meas, q, dq, ddq, positions, meas_err,
                        reinterpret_cast<unsigned long long*>(h->cmax));
     HIPCHK(hipGetLastError());
     std::vector<double> hc(B);
+    std::vector<SeqState> hs(B);
     HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(hc.data(), h->cmax, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    prof_collect(h);
     cpe_status worst = CPE_OK;
     for (int b = 0; b < B; b++) {
         const SeqState& S = hs[b];

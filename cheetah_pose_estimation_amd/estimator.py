@@ -24,6 +24,24 @@ import numpy as np
 from . import _lib, abi, skeleton
 
 
+class _ArrayOnlyUnpickler(pickle.Unpickler):
+    """`fte.pickle` reader that executes nothing from the file: only the globals a dict of numpy arrays / floats needs are
+    resolvable; anything else (a `fte.pickle` may come from an untrusted tree laid out like the reference's data) raises."""
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"fte.pickle: global {module}.{name} is not allowed (arrays, numbers, str, dict, list only)")
+
+
+def load_result_pickle(path: str) -> dict:
+    """read back a result file written by CheetahEstimator.save (plain dict of arrays and numbers)"""
+    with open(path, "rb") as fh:
+        return _ArrayOnlyUnpickler(fh).load()
+
+
 # ---- data classes mirroring acinoset_misc.py:40-73 ---------------------------------------------------
 @dataclass
 class TrajectoryParams:
@@ -242,8 +260,7 @@ class CheetahEstimator:
         params, scene, sk = self.params, self.scene, self.skeleton
         data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, self.data_path)
         sub = "fte_kinematic" if not monocular else f"fte_kinematic_{scene.cam_idx}"
-        with open(os.path.join(data_dir, sub, "fte.pickle"), "rb") as fh:          # written by CheetahEstimator.save above
-            fte = pickle.load(fh)
+        fte = load_result_pickle(os.path.join(data_dir, sub, "fte.pickle"))       # restricted unpickler: arrays and numbers only
         if contacts is None:
             with open(os.path.join(data_dir, "grf", "autogen-contact.json"), "r", encoding="utf-8") as fh:
                 contacts = json.load(fh)
@@ -426,8 +443,7 @@ def determine_contacts(estimator: CheetahEstimator, monocular: bool = False, ver
     params, scene, sk = estimator.params, estimator.scene, estimator.skeleton
     data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, estimator.data_path)
     sub = "fte_kinematic" if not monocular else f"fte_kinematic_{scene.cam_idx}"
-    with open(os.path.join(data_dir, sub, "fte.pickle"), "rb") as fh:              # written by CheetahEstimator.save
-        fte = pickle.load(fh)
+    fte = load_result_pickle(os.path.join(data_dir, sub, "fte.pickle"))           # restricted unpickler: arrays and numbers only
     estimator.com_vel, estimator.com_pos = fte["com_vel"], fte["com_pos"]
     h = _lib.Handle(sk, estimator.cams, device=estimator.device)
     try:

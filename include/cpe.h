@@ -155,6 +155,19 @@ void cpe_default_options(cpe_options* o);
 /* stream the handle launches on (hipStream_t as void*), for event timing by the caller */
 void* cpe_stream(cpe_handle* h);
 cpe_status cpe_synchronize(cpe_handle* h);
+/* Synchronisation contract of the device-pointer entry points: they only ENQUEUE work on the handle's own (non-blocking) stream
+ * and order nothing against any other stream.  A caller that produced the inputs on another stream (`other`, a hipStream_t as
+ * void*; NULL = the legacy default stream; e.g. torch's current stream) calls cpe_stream_wait before the entry point, and
+ * cpe_stream_signal after it when that stream will consume the outputs; or it calls cpe_synchronize.  (The reference is
+ * synchronous: Pyomo blocks on the IPOPT subprocess, acinoset_opt.py:611-617.) */
+cpe_status cpe_stream_wait(cpe_handle* h, void* other);     /* later launches of the handle wait for the work queued on `other` so far */
+cpe_status cpe_stream_signal(cpe_handle* h, void* other);   /* `other` waits for the work the handle has queued so far */
+/* per-kernel device time of cpe_solve / cpe_solve_kinetic, accumulated by HIP events on the handle's stream while enabled
+ * (what the reference stores as processing_time_s is one wall time around .solve(), acinoset_opt.py:610-618).
+ * slots: 0 k_frame_normal, 1 k_lr_band, 2 k_lm_step, 3 k_build_act, 4 k_finalize, 5 k_dyn_term, 6 k_dyn_gather, 7 other */
+#define CPE_PROFILE_SLOTS 8
+cpe_status cpe_profile_enable(cpe_handle* h, int32_t on);                              /* also clears the totals */
+cpe_status cpe_profile_get(cpe_handle* h, double* ms /*[8]*/, int64_t* launches /*[8]*/);
 
 /* number of Jacobian slots: the structurally non-zero (marker, dof) pairs, sum_l (3 + 3*chain_len(l)), followed by 0-3
  * structurally ZERO pairs (marker 0, a dof outside its chain; the stored value is 0) that round the count up to a multiple of 4,

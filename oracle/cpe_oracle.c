@@ -936,6 +936,28 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     return status;
 }
 
+/* bench.py's multi-thread CPU solve leg: B independent sequences, one cpo_solve each, spread over OpenMP threads (the way a
+ * CPU user of the reference would parallelise run_dataset.py's loop over sequences).  Returns the number of threads used;
+ * iterations[b] (optional) receives each solve's LM iteration count.  Outputs other than q are not kept. */
+int cpo_solve_batch(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr, int B, int N,
+                    const double* q_init, const double* meas, const double* weight, double* q, int threads, int* iterations) {
+    int nq = NQ(s), L = s->n_markers, used = 1;
+    if (threads < 1) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; b++) {
+            cpe_stats st;
+            cpo_solve(s, cams, C, o, pr, N, q_init + (size_t)b * N * nq, meas + (size_t)b * N * C * L * 2, weight + (size_t)b * N * C * L,
+                      q + (size_t)b * N * nq, NULL, NULL, NULL, NULL, &st);
+            if (iterations) iterations[b] = st.iterations;
+        }
+    }
+    return used;
+}
+
 /* reduced gradient / cost at a point (used by tests to check stationarity and by finite-difference checks) */
 double cpo_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
                      const cpe_priors* pr, int N, double* q /* made consistent with the joint equalities in place */,

@@ -85,6 +85,17 @@ def eval_resjac_batch(sk, cams, opts, q, meas, weight, reps=1, threads=1):
     return int(used), float(chk.value)
 
 
+def solve_batch(sk, cams, opts, q_init, meas, weight, threads=0, priors=None):
+    """bench.py's multi-thread CPU solve leg: q_init[B,N,nq] ... -> (threads used, q[B,N,nq], iterations[B])"""
+    q_init, meas, weight = _c(q_init), _c(meas), _c(weight)
+    B, N, Cn, L = weight.shape
+    q = np.empty_like(q_init)
+    its = np.zeros(B, dtype=np.int32)
+    used = lib().cpo_solve_batch(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, B, N,
+                                 _p(q_init), _p(meas), _p(weight), _p(q), int(threads), its.ctypes.data_as(C.POINTER(C.c_int32)))
+    return int(used), q, its
+
+
 def markers_jac(sk, q):
     q = _c(q)
     pos = np.empty((sk.n_markers, 3))

@@ -62,3 +62,24 @@ def test_initial_guess_checker_identities():
         Xa, Xb = P @ Ra.T + ta, P @ Rb.T + tb                     # exact normalised coordinates: tests the DLT alone
         X = G.triangulate(Xa[:, :2] / Xa[:, 2:], Xb[:, :2] / Xb[:, 2:], Ra, ta, Rb, tb)
         assert np.abs(X - P).max() < 1e-8, (a, b)
+
+
+def test_result_pickle_reader_executes_nothing(tmp_path):
+    """`fte.pickle` is read back with an unpickler that resolves numpy array globals only"""
+    import pickle
+    from cheetah_pose_estimation_amd import estimator as E
+    good = dict(q=np.arange(12.0).reshape(3, 4), obj_cost=np.float64(1.5), start_frame=7, tau={}, name="x", com_vel=None)
+    p = tmp_path / "fte.pickle"
+    with open(p, "wb") as f:
+        pickle.dump(good, f)
+    back = E.load_result_pickle(str(p))
+    assert np.array_equal(back["q"], good["q"]) and back["obj_cost"] == 1.5 and back["start_frame"] == 7
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+    with open(p, "wb") as f:
+        pickle.dump(dict(q=Evil()), f)
+    with pytest.raises(pickle.UnpicklingError):
+        E.load_result_pickle(str(p))

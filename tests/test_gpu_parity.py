@@ -356,18 +356,21 @@ def test_frame_normal_matches_oracle(sk25, cams6, oracle, gpu_handle_factory):
     assert saw_other_branch
 
 
-def test_solve_through_the_gimbal_region(cams6, oracle, gpu_handle_factory):
-    """limbs swinging beyond 90 degrees of pitch under a rolled trunk (both cos(phi) branches of the joint
-    equalities, as in the stored AcinoSet runs).  From a start near the truth HIP and oracle follow the same path in the
-    leg-angle coordinates and agree to fp64 round-off amplified by ~50 LM iterations.  (From the zero-angle initial
-    guess such an exaggerated swing is a hard non-convex problem whose early path is chaotic -- two runs of the same
-    algorithm with 1e-10 different Jacobians may settle in neighbouring minima -- so that case is not a parity test;
-    tests/test_oracle_math.py covers convergence from the far start on the CPU.)"""
+@pytest.mark.parametrize("lambda0", [None, 1e-3])
+def test_solve_through_the_gimbal_region(lambda0, cams6, oracle, gpu_handle_factory):
+    """limbs swinging beyond 90 degrees of pitch under a rolled trunk (both cos(phi) branches of the joint equalities, as in the
+    stored AcinoSet runs), from a start near the truth.  At the SHIPPED damping (lambda0 = 1e-4) the first steps through this
+    exaggerated swing are large enough for round-off to send the two implementations into neighbouring minima on one of the two
+    sequences (measured: costs 8e-4 apart, markers 0.11 mm apart): the statement there is BASELINE.json's bar, 1 mm RMSE.  With
+    the conservative start lambda0 = 1e-3 both follow one path and agree to round-off amplified by ~40 iterations.  (From the
+    zero-angle initial guess such a swing is a hard non-convex problem whose early path is chaotic, so that case is not a parity
+    test; tests/test_oracle_math.py covers convergence from the far start on the CPU.)"""
     sk = skeleton.build_skeleton("phantom", 25)
     sk.n_bounds = 0
     opts = abi.default_options()
-    opts.lambda0 = 1e-3        # conservative start: with the default 1e-4 the first steps through this exaggerated swing are large
-    #                            enough for round-off to send the two implementations into neighbouring minima (costs 0.07 % apart)
+    if lambda0 is not None:
+        opts.lambda0 = lambda0
+    assert lambda0 is not None or opts.lambda0 == 1e-4           # None = whatever ships
     h = gpu_handle_factory(sk, cams6, opts)
     d = synth.make_batch(sk, cams6, B=2, N=24, seed=61, wide_limbs=True)
     near = d["q_true"] + np.random.default_rng(0).normal(0, 0.01, d["q_true"].shape)
@@ -377,8 +380,12 @@ def test_solve_through_the_gimbal_region(cams6, oracle, gpu_handle_factory):
         ref = oracle.solve(sk, cams6, opts, None, near[b], d["meas"][b], d["weight"][b])
         assert out["stats"][b].status == abi.OK and ref["stats"].status == abi.OK
         rmse = np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean())
-        assert rmse < 1e-4, rmse
-        assert abs(out["stats"][b].cost - ref["stats"].cost) < 1e-7 * abs(ref["stats"].cost)
+        if lambda0 is None:
+            assert rmse < 1e-3, rmse                                                       # the 1 mm bar
+            assert abs(out["stats"][b].cost - ref["stats"].cost) < 2e-3 * abs(ref["stats"].cost)
+        else:
+            assert rmse < 1e-5, rmse
+            assert abs(out["stats"][b].cost - ref["stats"].cost) < 1e-7 * abs(ref["stats"].cost)
         c = np.array([np.abs(oracle.constraints(sk, x)).max() for x in out["q"][b]])
         assert c.max() < 1e-12
         seen += int((np.abs(out["q"][b][:, 3::3][:, 5:]) > np.pi / 2).sum())
@@ -468,31 +475,58 @@ def test_monocular_solve_with_learned_priors(cams6, oracle, gpu_handle_factory):
         assert max(np.abs(oracle.constraints(sk, x)).max() for x in out["q"][b]) < 1e-12
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 9])
-def test_solve_short_sequences(N, sk25, cams6, oracle, gpu_handle_factory):
-    """sequences shorter than the band (no motion term for N < 4, partial windows for N < 8): the sliding-window
-    factorisation must degrade gracefully.  Without the motion coupling a frame with 10 % outliers has nearly flat
-    directions (both implementations then creep for > 100 iterations and may stop centimetres apart along them at equal
-    cost), so the positions are compared only where the solve is quick; the objective value is compared always."""
+def test_monocular_config3_200_frames(cams6, oracle, gpu_handle_factory):
+    """config 3 at the benchmark length: ONE camera, GMM pose prior + window-4 motion prior, N = 200.  Unlike the 40-frame case
+    above, 200 frames of motion prior make the problem well posed: HIP and oracle reach the same minimiser -- status OK on both
+    sides, marker RMSE under BASELINE.json's 1 mm bar (measured 9e-11 m and 8e-5 m), cost to 1e-4."""
+    from cheetah_pose_estimation_amd import priors
+    sk = skeleton.build_skeleton("phantom", 24)
+    pr = priors.load_priors()
+    cam1 = (abi.Camera * 1)(cams6[2])
+    opts = abi.default_options()
+    h = gpu_handle_factory(sk, cam1, opts, pr)
+    d = synth.make_batch(sk, cam1, B=2, N=200, seed=5, init_noise=0.03)
+    out = h.solve_host(d["q_init"], d["meas"], d["weight"])
+    for b in range(2):
+        st = out["stats"][b]
+        ref = oracle.solve(sk, cam1, opts, pr, d["q_init"][b], d["meas"][b], d["weight"][b])
+        assert st.status == abi.OK and ref["stats"].status == abi.OK
+        rmse = np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean())
+        assert rmse < 1e-3, rmse
+        assert abs(st.cost - ref["stats"].cost) < 1e-4 * abs(ref["stats"].cost)
+        assert max(np.abs(oracle.constraints(sk, x)).max() for x in out["q"][b]) < 1e-12
+
+
+# (N, sequence) pairs that are NOT parity cases, measured on MI355X in round 2 (gpurun_out/r2_exp_tests.log): without the motion
+# coupling (N < 4 has no acceleration term) a frame with 10 % outliers has nearly flat directions; HIP and oracle then BOTH creep
+# to the 200-iteration limit and stop centimetres apart at costs that agree to 3e-4 ... 9 %.  They are recorded as expected failures
+# of the parity statement instead of being waved through.
+_SHORT_CREEP = {(2, 1), (3, 0), (3, 1)}
+
+
+@pytest.mark.parametrize("N,b", [(N, b) for N in (1, 2, 3, 4, 5, 9) for b in (0, 1)])
+def test_solve_short_sequences(N, b, sk25, cams6, oracle, gpu_handle_factory):
+    """sequences shorter than the band (no motion term for N < 4, partial windows for N < 8): the sliding-window factorisation
+    must degrade gracefully.  Every (N, sequence) case states parity explicitly: same status, same iteration count +-2, cost to
+    1e-6, positions to 1e-5 m; the three creeping cases are xfail (see _SHORT_CREEP)."""
     opts = abi.default_options()
     h = gpu_handle_factory(sk25, cams6, opts)
     d = synth.make_batch(sk25, cams6, B=2, N=N, seed=7)
     out = h.solve_host(d["q_init"], d["meas"], d["weight"])
-    quick = 0
-    for b in range(2):
-        ref = oracle.solve(sk25, cams6, opts, None, d["q_init"][b], d["meas"][b], d["weight"][b])
-        st, rs = out["stats"][b], ref["stats"]
-        assert st.status in (abi.OK, abi.MAX_ITER) and np.isfinite(out["q"][b]).all()
-        # whatever path was taken, the reported cost is the oracle's objective at the returned trajectory
-        terms = oracle.objective(sk25, cams6, opts, None, out["q"][b], d["meas"][b], d["weight"][b])[3]
-        assert abs(st.cost - opts.cost_scale * (terms[0] + terms[1])) < 1e-9 * abs(st.cost)     # measurement + model (the bound term is not part of obj_cost)
-        assert abs(st.cost - rs.cost) < 0.1 * abs(rs.cost)                 # neighbouring minima of the redescending loss at worst
-        if rs.iterations < 80 and st.iterations < 80 and abs(st.iterations - rs.iterations) <= 1:
-            quick += 1
-            assert st.status == rs.status == abi.OK
-            assert abs(st.cost - rs.cost) < 1e-6 * abs(rs.cost)
-            assert np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-5
-    assert quick >= 1 or N in (1, 2, 3, 5)
+    ref = oracle.solve(sk25, cams6, opts, None, d["q_init"][b], d["meas"][b], d["weight"][b])
+    st, rs = out["stats"][b], ref["stats"]
+    assert st.status in (abi.OK, abi.MAX_ITER) and np.isfinite(out["q"][b]).all()
+    # whatever path was taken, the reported cost is the oracle's objective at the returned trajectory
+    terms = oracle.objective(sk25, cams6, opts, None, out["q"][b], d["meas"][b], d["weight"][b])[3]
+    assert abs(st.cost - opts.cost_scale * (terms[0] + terms[1])) < 1e-9 * abs(st.cost)     # measurement + model (the bound term is not part of obj_cost)
+    assert st.status == rs.status
+    if (N, b) in _SHORT_CREEP:
+        assert st.status == abi.MAX_ITER                                   # both implementations creep to the limit
+        pytest.xfail("flat directions without the motion coupling: both implementations stop at the iteration limit, apart")
+    assert st.status == abi.OK
+    assert abs(st.iterations - rs.iterations) <= 2
+    assert abs(st.cost - rs.cost) < 1e-6 * abs(rs.cost)
+    assert np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-5
 
 
 def test_solve_is_reproducible_and_independent_of_batching(sk25, cams6, gpu_handle_factory):
