@@ -81,6 +81,10 @@ def load():
     lib.cpe_eom_rows.argtypes = [vp, C.POINTER(abi.EomOptions), C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.cpe_eom_residual.argtypes = [vp, C.POINTER(abi.DynOptions), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_grf_fit.argtypes = [vp, C.POINTER(abi.GrfOptions), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    lib.cpe_default_kinetic_options.argtypes = [C.POINTER(abi.KineticOptions), C.c_double, C.c_int32]
+    lib.cpe_default_kinetic_options.restype = None
+    lib.cpe_solve_kinetic.argtypes = [vp, C.POINTER(abi.KineticOptions), C.c_int32, C.c_int32] + [vp] * 13 + [C.POINTER(abi.Stats), C.POINTER(abi.KineticStats)]
+    lib.cpe_eval_kinetic_nodes.argtypes = [vp, C.POINTER(abi.KineticOptions), C.c_int32, C.c_int32] + [vp] * 11
     _LIB = lib
     return lib
 
@@ -316,6 +320,58 @@ class Handle:
         self.grf_fit(gopt, qd, dqd, ddqd, cd, gz, gxy, res)
         self.synchronize()
         return gz.cpu().numpy(), gxy.cpu().numpy(), res.cpu().numpy()
+
+    # ---- physics-based trajectory model (config 4) -------------------------------------------------------
+    def solve_kinetic(self, kopts, q_init, meas, weight, stance, q, dq, ddq, positions, meas_err, tau=None, lam=None, grf=None, slack=None):
+        """device tensors (stance int32 [B, N, n_feet]); returns (status, [Stats], [KineticStats])"""
+        B, N = q_init.shape[0], q_init.shape[1]
+        stats = (abi.Stats * max(B, 1))(); ks = (abi.KineticStats * max(B, 1))()
+        self._enter()
+        st = self.lib.cpe_solve_kinetic(self._h, C.byref(kopts), B, N, _ptr(q_init), _ptr(meas), _ptr(weight), _ptr(stance), _ptr(q), _ptr(dq), _ptr(ddq),
+                                        _ptr(positions), _ptr(meas_err), _ptr(tau), _ptr(lam), _ptr(grf), _ptr(slack), stats, ks)
+        self._leave()
+        _check(st, "cpe_solve_kinetic", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
+        return st, list(stats)[:B], list(ks)[:B]
+
+    def n_constraint_rows(self):
+        return sum(2 if self.sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y else 1 for j in range(self.sk.n_joints))
+
+    def solve_kinetic_host(self, kopts, q_init, meas, weight, stance):
+        """numpy in, numpy out (staged through HBM with torch)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        T = lambda a, dt=np.float64: torch.tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+        qi, me, we, stn = T(q_init), T(meas), T(weight), T(stance, np.int32)
+        B, N = qi.shape[0], qi.shape[1]
+        E = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        nm, nf, nc = kopts.dyn.n_motors, kopts.dyn.n_feet, self.n_constraint_rows()
+        q, dq, ddq = E(B, N, self.nq), E(B, N, self.nq), E(B, N, self.nq)
+        pos, err = E(B, N, self.L, 3), E(B, N, self.n_cams, self.L, 2)
+        tau, lam, grf, slack = E(B, N, nm), E(B, N, nc), E(B, N, nf, 5), E(B, N, self.nq)
+        st, stats, ks = self.solve_kinetic(kopts, qi, me, we, stn, q, dq, ddq, pos, err, tau, lam, grf, slack)
+        self.synchronize()
+        c = lambda t: t.cpu().numpy()
+        return dict(status=st, q=c(q), dq=c(dq), ddq=c(ddq), positions=c(pos), meas_err=c(err), tau=c(tau), lam=c(lam), grf=c(grf), slack=c(slack),
+                    stats=stats, kstats=ks)
+
+    def eval_kinetic_nodes_host(self, kopts, q, meas, weight, stance):
+        """one evaluation of the physics terms per node (cpe_eval_kinetic_nodes); numpy in, dict of numpy arrays out"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        T = lambda a, dt=np.float64: torch.tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+        qd, me, we, stn = T(q), T(meas), T(weight), T(stance, np.int32)
+        B, N = qd.shape[0], qd.shape[1]
+        E = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+        out = dict(f=E(B, N, 64), stat=E(B, N, 8), g=E(B, N, 84), Huu=E(B, N, 84, 84), Hfu=E(B, N, 64, 84), Hff=E(B, N, 64, 64))
+        meta = torch.zeros((B, N, 65), dtype=torch.int32, device=dev)
+        self._enter()
+        _check(self.lib.cpe_eval_kinetic_nodes(self._h, C.byref(kopts), B, N, _ptr(qd), _ptr(me), _ptr(we), _ptr(stn), _ptr(out["f"]), _ptr(out["stat"]),
+                                               _ptr(out["g"]), _ptr(out["Huu"]), _ptr(out["Hfu"]), _ptr(out["Hff"]), _ptr(meta)), "cpe_eval_kinetic_nodes")
+        self._leave()
+        self.synchronize()
+        res = {k: v.cpu().numpy() for k, v in out.items()}
+        res["meta"] = meta.cpu().numpy()
+        return res
 
     # ---- host-pointer conveniences (numpy in, numpy out; PCIe-inclusive) -------------------------------
     def eval_resjac_host(self, q, meas, weight, want_cost=True):

@@ -104,6 +104,36 @@ class DynOptions(C.Structure):
                 ("motor_first", C.c_int32 * 32), ("motor_second", C.c_int32 * 32), ("motor_axis", C.c_int32 * 32)]
 
 
+class KineticOptions(C.Structure):
+    """mirror of cpe_kinetic_options (include/cpe.h): the physics-based trajectory model of estimate_kinetics"""
+    _fields_ = [("dyn", DynOptions), ("w_slack", C.c_double), ("w_torque", C.c_double), ("w_smooth", C.c_double), ("friction", C.c_double),
+                ("force_max", C.c_double), ("grfz_min", C.c_double), ("foot_height_tol", C.c_double), ("foot_height_min", C.c_double),
+                ("ground_height", C.c_double), ("slip_max", C.c_double), ("slack_bound", C.c_double), ("reg_force", C.c_double),
+                ("kappa_force", C.c_double), ("kappa_height", C.c_double), ("kappa_slip", C.c_double), ("fd_step", C.c_double),
+                ("lm_damping", C.c_double), ("lm_force_damping", C.c_double), ("inner_iterations", C.c_int32), ("_pad", C.c_int32)]
+
+
+class KineticStats(C.Structure):
+    """mirror of cpe_kinetic_stats (include/cpe.h)"""
+    _fields_ = [("cost_torque", C.c_double), ("cost_energy", C.c_double), ("cost_eom", C.c_double), ("max_slack", C.c_double),
+                ("max_base_rows", C.c_double), ("max_violation", C.c_double), ("inner_max", C.c_int32), ("_pad", C.c_int32)]
+
+
+def default_kinetic_options(dyn: DynOptions, fps: float = 120.0, kinetic_dataset: bool = False) -> KineticOptions:
+    """the reference's values (acinoset_opt.py:494-506, :780, :905-921; acinoset_misc.py:1140-1167; run_dataset.py:984); same numbers as
+    cpe_default_kinetic_options() in csrc/cpe_api.hip"""
+    o = KineticOptions()
+    C.memmove(C.byref(o.dyn), C.byref(dyn), C.sizeof(DynOptions))
+    o.w_slack, o.w_torque, o.w_smooth = 10e3, 1.0, 0.1 / (fps * fps)
+    o.friction, o.force_max, o.grfz_min = 0.8, 5.0, 0.01
+    o.foot_height_tol = 0.03 if kinetic_dataset else 0.1
+    o.foot_height_min, o.ground_height, o.slip_max, o.slack_bound = 0.0, 0.0, 1.0, 2.0
+    o.reg_force, o.kappa_force, o.kappa_height, o.kappa_slip, o.fd_step = 1e-4, 1e5, 1e6, 1e2, 1e-6
+    o.lm_damping, o.lm_force_damping = 0.0, 1.0
+    o.inner_iterations = 30
+    return o
+
+
 def default_options(fps: float = 120.0) -> Options:
     """Same defaults as cpe_default_options() in csrc/cpe_api.cpp."""
     o = Options()

@@ -49,6 +49,12 @@ struct cpe_handle {
     DevPriors* pri = nullptr;    // device copy, nullptr without priors
     int gmm_k = 0, gmm_dim = 0, lr_window = 0;
     double* Hlr = nullptr;       // [2][F][pb][nu*nu] off-diagonal Gauss-Newton blocks of the autoregressive prior
+    // physics-based model (cpe_solve_kinetic): device options and workspace
+    DevKin* dk = nullptr; DevKin hk;
+    size_t kws_frames = 0;
+    double *fbuf = nullptr, *kmu = nullptr, *Jbuf = nullptr, *Abuf = nullptr, *pieces = nullptr, *gTb = nullptr, *dstat = nullptr, *slackb = nullptr,
+           *Tbuf = nullptr, *gk = nullptr, *Bk = nullptr, *Hk = nullptr;
+    int* pmeta = nullptr;
     int pb = 3;                  // half-bandwidth of the normal equations in frames (4 with a window-4 motion prior)
 };
 
@@ -425,7 +431,15 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
     return CPE_OK;
 }
 
+static void free_kws(cpe_handle* h) {
+    void* ptrs[] = {h->fbuf, h->kmu, h->Jbuf, h->Abuf, h->pieces, h->gTb, h->dstat, h->slackb, h->Tbuf, h->gk, h->Bk, h->Hk, h->pmeta};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->fbuf = h->kmu = h->Jbuf = h->Abuf = h->pieces = h->gTb = h->dstat = h->slackb = h->Tbuf = h->gk = h->Bk = h->Hk = nullptr; h->pmeta = nullptr;
+    h->kws_frames = 0;
+}
+
 static void free_ws(cpe_handle* h) {
+    free_kws(h);
     void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st, h->Hlr, h->act};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = h->Hlr = nullptr; h->st = nullptr; h->act = nullptr;
@@ -441,6 +455,7 @@ void cpe_destroy(cpe_handle* h) {
     if (h->pri) (void)hipFree(h->pri);
     if (h->eom) (void)hipFree(h->eom);
     if (h->dyn) (void)hipFree(h->dyn);
+    if (h->dk) (void)hipFree(h->dk);
     if (h->n_act) (void)hipFree(h->n_act);
     if (h->poll_host) (void)hipHostFree(h->poll_host);
     for (int i = 0; i < 2; i++) if (h->poll_ev[i]) (void)hipEventDestroy(h->poll_ev[i]);
@@ -829,6 +844,243 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
         }
     }
     return worst;
+}
+
+
+// ---- physics-based trajectory model (include/cpe.h, cpe_solve_kinetic) -------------------------------------------------------------
+void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kinetic_dataset) {
+    // o->dyn (inertias, feet, motors) is the caller's
+    o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
+    o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->slack_bound = 2.0;
+    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_damping = 0.0; o->lm_force_damping = 1.0;
+    o->inner_iterations = 30; o->_pad = 0;
+}
+
+static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt) {
+    const DevModel& m = h->hm;
+    DevKin& K = h->hk;
+    memset(&K, 0, sizeof(K));
+    K.o = *opt;
+    const cpe_dyn_options& d = opt->dyn;
+    if (d.n_feet < 1 || d.n_feet > 4 || d.n_motors < 0 || d.n_motors > CPE_MAX_MOTORS) return fail(CPE_BAD_ARG, "kinetic options: feet / motors out of range");
+    for (int f = 0; f < d.n_feet; f++) if (d.foot_marker[f] < 0 || d.foot_marker[f] >= m.L) return fail(CPE_BAD_ARG, "foot marker index out of range");
+    for (int k = 0; k < d.n_motors; k++)
+        if (d.motor_first[k] < 0 || d.motor_first[k] >= m.nl || d.motor_second[k] < 0 || d.motor_second[k] >= m.nl || d.motor_axis[k] < 0 || d.motor_axis[k] > 2)
+            return fail(CPE_BAD_ARG, "motor definition out of range");
+    if (!(opt->w_slack > 0) || !(opt->kappa_force > 0) || !(opt->kappa_height > 0) || !(opt->kappa_slip > 0) || !(opt->fd_step > 0) || !(opt->reg_force > 0) ||
+        !(d.eom.gravity > 0) || opt->inner_iterations < 1)
+        return fail(CPE_BAD_ARG, "kinetic options: weights, penalties, step and gravity must be positive");
+    for (int k = 0; k < m.nu; k++) if (m.motion_w_u[k] != 0.0) return fail(CPE_BAD_ARG, "the physics-based model replaces the constant-acceleration cost: motion_w must be zero");
+    if (h->lr_window > 0) return fail(CPE_BAD_ARG, "the physics-based model does not use the autoregressive motion prior (acinoset_opt.py:905-921)");
+    K.nm = d.n_motors; K.nf = d.n_feet; K.nc = 0;
+    for (int j = 0; j < m.nj; j++)
+        for (int t = (m.joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 0 : 1); t < 2; t++) { K.con_joint[K.nc] = j; K.con_axis[K.nc] = t == 0 ? 0 : 2; K.nc++; }
+    K.nlat = K.nm + K.nc + 3 * K.nf;
+    if (K.nlat > KIN_LS || K.nm + K.nc > 52) return fail(CPE_BAD_ARG, "more than 64 node forces");
+    K.nrow = m.nq + 3 * K.nf + 3 * m.L;
+    if (m.nl > 32 || m.L > 32 || m.nrev > 32 || K.nrow > KIN_ROWS_MAX) return fail(CPE_BAD_ARG, "skeleton too large for the kinetic kernels");
+    double mt = 0; for (int i = 0; i < m.nl; i++) mt += m.mass[i];
+    K.Mg = mt * d.eom.gravity; K.h = h->opts.h; K.ih = 1.0 / h->opts.h;
+    for (int i = 0; i < m.nl; i++) { uint32_t mask = 0; for (int j = 0; j < m.nl; j++) { int a = j; while (a >= 0 && a != i) a = m.parent[a]; if (a == i) mask |= 1u << j; } K.sub_mask[i] = mask; }
+    if (!h->dk) HIPCHK(hipMalloc(&h->dk, sizeof(DevKin)));
+    HIPCHK(hipMemcpyAsync(h->dk, &K, sizeof(DevKin), hipMemcpyHostToDevice, h->stream));
+    return CPE_OK;
+}
+
+static size_t lds_kin_eval() {
+    const size_t x = std::max<size_t>(8 * (size_t)KIN_SLOT, 2 * (size_t)KIN_LS * KIN_LS + 2048);
+    return sizeof(double) * ((sizeof(KinShared) + 7) / 8 + (size_t)CPE_MAX_NQ * KIN_LS + x);
+}
+static size_t lds_kin_assemble() { return sizeof(double) * ((size_t)KIN_ROWS_MAX * KIN_NC3 + (size_t)CPE_MAX_NQ * KIN_LS + 2 * KIN_ROWS_MAX); }
+static size_t lds_kin_schur() { return sizeof(double) * ((size_t)KIN_LS * KIN_LS + (size_t)KIN_LS * KIN_NC3); }
+
+static cpe_status ensure_kws(cpe_handle* h, int B, int N) {
+    const size_t F = (size_t)B * N;
+    if (F <= h->kws_frames) return CPE_OK;
+    free_kws(h);
+    const int BB = CPE_NX * CPE_NX;
+    HIPCHK(hipMalloc(&h->fbuf, sizeof(double) * 2 * F * KIN_LS));
+    HIPCHK(hipMalloc(&h->kmu, sizeof(double) * F * 4 * KIN_MU));
+    HIPCHK(hipMalloc(&h->Jbuf, sizeof(double) * F * KIN_JSTRIDE));
+    HIPCHK(hipMalloc(&h->Abuf, sizeof(double) * F * CPE_MAX_NQ * KIN_LS));
+    HIPCHK(hipMalloc(&h->pieces, sizeof(double) * 2 * F * KIN_PIECE));
+    HIPCHK(hipMalloc(&h->pmeta, sizeof(int) * 2 * F * (KIN_LS + 1)));
+    HIPCHK(hipMalloc(&h->gTb, sizeof(double) * 2 * (F + 2) * KIN_NC3));
+    HIPCHK(hipMalloc(&h->dstat, sizeof(double) * 2 * F * KIN_STAT));
+    HIPCHK(hipMalloc(&h->slackb, sizeof(double) * 2 * F * CPE_MAX_NQ));
+    HIPCHK(hipMalloc(&h->Tbuf, sizeof(double) * (F + 2) * 6 * BB));
+    HIPCHK(hipMalloc(&h->gk, sizeof(double) * F * CPE_NX));
+    HIPCHK(hipMalloc(&h->Bk, sizeof(double) * F * BB));
+    HIPCHK(hipMalloc(&h->Hk, sizeof(double) * F * 3 * BB));
+    const void* ks[] = {(const void*)&k_dyn_eval, (const void*)&k_dyn_assemble, (const void*)&k_dyn_schur};
+    for (const void* k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->kws_frames = F;
+    return CPE_OK;
+}
+
+// one evaluation pass of the physics terms on the evaluated buffer (after k_frame_normal)
+static void launch_dyn_eval(cpe_handle* h, int N, int first, size_t Fw, const int32_t* stance, const int* act, const int* n_act, int slots) {
+    const unsigned gf = (unsigned)((size_t)slots * N);
+    prof_begin(h, 5);
+    hipLaunchKernelGGL(k_dyn_eval, dim3(gf), dim3(KIN_THREADS), lds_kin_eval(), h->stream, h->dm, h->dk, h->st, N, first, Fw, h->qbuf, stance, h->fbuf, h->kmu, h->costbuf,
+                       h->Jbuf, h->Abuf, h->pieces, h->pmeta, h->dstat, h->slackb, act, n_act);
+    hipLaunchKernelGGL(k_dyn_assemble, dim3(gf), dim3(KIN_THREADS), lds_kin_assemble(), h->stream, h->dm, h->dk, h->st, N, first, Fw, h->Jbuf, h->Abuf, h->pieces, h->pmeta,
+                       h->gTb, act, n_act);
+    prof_end(h);
+}
+
+cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                             const double* weight, const int32_t* stance, double* q, double* dq, double* ddq, double* positions,
+                             double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats, cpe_kinetic_stats* kstats) {
+    if (!h || !opt || !q_init || !meas || !weight || !stance || !q) return fail(CPE_BAD_ARG, "null argument");
+    if ((dq == nullptr) != (ddq == nullptr)) return fail(CPE_BAD_ARG, "dq and ddq must be given together");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    if (h->pb != 3) return fail(CPE_BAD_ARG, "the physics-based model runs on the half-bandwidth-3 solver");
+    HIPCHK(hipSetDevice(h->device));
+    cpe_status s = build_kin(h, opt);
+    if (s != CPE_OK) return s;
+    s = ensure_ws(h, B, N);
+    if (s != CPE_OK) return s;
+    s = ensure_kws(h, B, N);
+    if (s != CPE_OK) return s;
+    const DevModel& m = h->hm;
+    const size_t Fw = F;
+    hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q_init, h->qbuf);
+    HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
+    HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
+    HIPCHK(hipMemsetAsync(h->fbuf, 0, sizeof(double) * 2 * F * KIN_LS, h->stream));
+    HIPCHK(hipMemsetAsync(h->kmu, 0, sizeof(double) * F * 4 * KIN_MU, h->stream));
+    LmParams prm;
+    prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
+    prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;
+    const size_t ldsn = lds_normal(m, h->gmm_k, h->gmm_dim);
+    // One iteration: per-frame terms and physics terms of the evaluated buffer, accept / reject (new damping), elimination of the node
+    // forces at that damping for the CURRENT iterate, band system, factor + solve + next trial.
+    auto iterate = [&](int first, const int* act, const int* n_act, int slots) {
+        const unsigned gf = (unsigned)((size_t)slots * N);
+        prof_begin(h, 0);
+        hipLaunchKernelGGL(k_frame_normal, dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
+                           h->costbuf, h->mu, h->gambuf, h->pri, act, n_act);
+        prof_end(h);
+        launch_dyn_eval(h, N, first, Fw, stance, act, n_act, slots);
+        prof_begin(h, 2);
+        hipLaunchKernelGGL((k_lm_step<3, 1>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
+                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, nullptr, act, n_act, 2);
+        prof_end(h);
+        prof_begin(h, 6);
+        hipLaunchKernelGGL(k_dyn_schur, dim3(gf), dim3(KIN_THREADS), lds_kin_schur(), h->stream, h->dk, h->st, N, Fw, h->pieces, h->pmeta, h->Tbuf, act, n_act);
+        hipLaunchKernelGGL(k_dyn_gather, dim3(gf), dim3(KIN_THREADS), 0, h->stream, h->st, N, Fw, h->gbuf, h->Bbuf, h->Tbuf, h->gTb, h->gk, h->Bk, h->Hk, act, n_act);
+        prof_end(h);
+        prof_begin(h, 2);
+        hipLaunchKernelGGL((k_lm_step<3, 2>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gk, h->Bk, h->costbuf,
+                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hk, act, n_act, 1);
+        prof_end(h);
+    };
+    iterate(1, nullptr, nullptr, B);
+    HIPCHK(hipGetLastError());
+    const int window = std::min(B, h->n_cu * 2);
+    constexpr int POLL = 4;
+    const long per_seq = (long)h->opts.max_iter + 2L * (h->opts.max_outer > 0 ? h->opts.max_outer : 0) + POLL;
+    const long max_rounds = ((long)(B + window - 1) / window + 1) * per_seq;
+    bool pending[2] = {false, false};
+    int slot = 0;
+    for (long it = 0; it < max_rounds; it += POLL) {
+        for (int k = 0; k < POLL; k++) {
+            hipLaunchKernelGGL(k_build_act, dim3(1), dim3(256), 0, h->stream, h->st, B, window, h->act, h->n_act);
+            iterate(0, h->act, h->n_act, window);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->poll_host + slot, h->n_act, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->poll_ev[slot], h->stream));
+        pending[slot] = true;
+        const int prev = 1 - slot;
+        if (pending[prev]) {
+            HIPCHK(hipEventSynchronize(h->poll_ev[prev]));
+            pending[prev] = false;
+            if (h->poll_host[prev] == 0) break;
+        }
+        slot = prev;
+    }
+    HIPCHK(hipMemsetAsync(h->cmax, 0, sizeof(double) * B, h->stream));
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, Fw, h->qbuf, meas, q, dq, ddq, positions, meas_err,
+                       reinterpret_cast<unsigned long long*>(h->cmax));
+    hipLaunchKernelGGL(k_dyn_outputs, dim3((unsigned)F), dim3(64), 0, h->stream, h->dk, h->st, N, Fw, h->fbuf, h->Abuf, nullptr, tau, lambda, grf);
+    HIPCHK(hipGetLastError());
+    std::vector<double> hc(B);
+    std::vector<SeqState> hs(B);
+    HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hc.data(), h->cmax, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    prof_collect(h);
+    // slack and the per-node statistics live in the buffer of each sequence's final iterate
+    std::vector<double> hd;
+    if (kstats) hd.resize(2 * F * KIN_STAT);
+    if (kstats) HIPCHK(hipMemcpyAsync(hd.data(), h->dstat, sizeof(double) * 2 * F * KIN_STAT, hipMemcpyDeviceToHost, h->stream));
+    if (slack)
+        for (int b = 0; b < B; b++)
+            HIPCHK(hipMemcpy2DAsync(slack + (size_t)b * N * m.nq, sizeof(double) * m.nq, h->slackb + ((size_t)hs[b].cur * F + (size_t)b * N) * CPE_MAX_NQ,
+                                    sizeof(double) * CPE_MAX_NQ, sizeof(double) * m.nq, N, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    cpe_status worst = CPE_OK;
+    for (int b = 0; b < B; b++) {
+        const SeqState& S = hs[b];
+        const cpe_status sb = S.status == 1 ? CPE_OK : ((S.status == 0 || S.status == 3) ? CPE_MAX_ITER : CPE_NUMERICAL);
+        if (sb > worst) worst = sb;
+        if (stats) {
+            cpe_stats& o = stats[b];
+            o.status = sb; o.iterations = S.iters; o.lambda = S.lambda; o.max_constraint = hc[b];
+            o.max_bound_violation = S.maxviol; o.outer = S.outer; o._pad = 0;
+            o.cost_meas = S.terms[0]; o.cost_model = S.terms[4]; o.cost_pose = S.terms[3]; o.cost_motion = 0.0;
+            o.cost = h->opts.cost_scale * (S.terms[0] + S.terms[3] + S.terms[4]);
+        }
+        if (kstats) {
+            cpe_kinetic_stats& k = kstats[b];
+            memset(&k, 0, sizeof(k));
+            for (int n = 0; n < N; n++) {
+                const double* d = hd.data() + ((size_t)S.cur * F + (size_t)b * N + n) * KIN_STAT;
+                k.cost_eom += d[0]; k.cost_torque += d[1]; k.cost_energy += d[3];
+                k.max_slack = std::max(k.max_slack, d[5]); k.max_base_rows = std::max(k.max_base_rows, d[6]); k.max_violation = std::max(k.max_violation, d[7]);
+            }
+        }
+    }
+    return worst;
+}
+
+// diagnostic building block (as cpe_eval_normal): one evaluation of the physics terms at Euler q, multipliers zero, forces from a cold start.
+// Device pointers: f [B][N][64] node forces, stat [B][N][8], g [B][N][84], Huu [B][N][84][84], Hfu [B][N][64][84], Hff [B][N][64][64];
+// meta int32 [B][N][65] = (number of free node forces, their indices).  (What ASL would hand IPOPT for the physics constraints of one node.)
+cpe_status cpe_eval_kinetic_nodes(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
+                                  const int32_t* stance, double* f, double* stat, double* g, double* Huu, double* Hfu, double* Hff, int32_t* meta) {
+    if (!h || !opt || !q || !meas || !weight || !stance) return fail(CPE_BAD_ARG, "null argument");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    cpe_status s = build_kin(h, opt);
+    if (s != CPE_OK) return s;
+    if ((s = ensure_ws(h, B, N)) != CPE_OK) return s;
+    if ((s = ensure_kws(h, B, N)) != CPE_OK) return s;
+    const DevModel& m = h->hm;
+    hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q, h->qbuf);
+    HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
+    HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
+    HIPCHK(hipMemsetAsync(h->fbuf, 0, sizeof(double) * 2 * F * KIN_LS, h->stream));
+    HIPCHK(hipMemsetAsync(h->kmu, 0, sizeof(double) * F * 4 * KIN_MU, h->stream));
+    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr);
+    launch_dyn_eval(h, N, 1, F, stance, nullptr, nullptr, B);
+    HIPCHK(hipGetLastError());
+    if (f) HIPCHK(hipMemcpyAsync(f, h->fbuf, sizeof(double) * F * KIN_LS, hipMemcpyDeviceToDevice, h->stream));
+    if (stat) HIPCHK(hipMemcpyAsync(stat, h->dstat, sizeof(double) * F * KIN_STAT, hipMemcpyDeviceToDevice, h->stream));
+    if (g) HIPCHK(hipMemcpyAsync(g, h->gTb, sizeof(double) * F * KIN_NC3, hipMemcpyDeviceToDevice, h->stream));
+    if (meta) HIPCHK(hipMemcpyAsync(meta, h->pmeta, sizeof(int) * F * (KIN_LS + 1), hipMemcpyDeviceToDevice, h->stream));
+    const size_t w = sizeof(double);
+    if (Huu) HIPCHK(hipMemcpy2DAsync(Huu, w * KIN_NC3 * KIN_NC3, h->pieces, w * KIN_PIECE, w * KIN_NC3 * KIN_NC3, F, hipMemcpyDeviceToDevice, h->stream));
+    if (Hfu) HIPCHK(hipMemcpy2DAsync(Hfu, w * KIN_LS * KIN_NC3, h->pieces + KIN_NC3 * KIN_NC3, w * KIN_PIECE, w * KIN_LS * KIN_NC3, F, hipMemcpyDeviceToDevice, h->stream));
+    if (Hff) HIPCHK(hipMemcpy2DAsync(Hff, w * KIN_LS * KIN_LS, h->pieces + KIN_NC3 * KIN_NC3 + KIN_LS * KIN_NC3, w * KIN_PIECE, w * KIN_LS * KIN_LS, F, hipMemcpyDeviceToDevice, h->stream));
+    return CPE_OK;
 }
 
 #ifdef CPE_LM_STAMPS

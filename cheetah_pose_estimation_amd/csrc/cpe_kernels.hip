@@ -559,3 +559,4 @@ __global__ __launch_bounds__(WAVE) void k_project(const DevModel* __restrict__ M
 }
 
 #include "cpe_solver.hip.inc"
+#include "cpe_kinetic.hip.inc"

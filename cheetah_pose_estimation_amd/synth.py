@@ -253,3 +253,135 @@ def make_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0,
         for i in range(sk.n_links):
             q_init[b, :, 3 + 3 * i + 2] = psi
     return dict(q_true=q_true, q_init=q_init, meas=np.ascontiguousarray(meas), weight=np.ascontiguousarray(weight))
+
+
+# ---------------------------------------------------------------------------------------------------
+# config 4 ("contact schedule = 4 feet rotary gallop 3 Hz, stance 12 frames"): a gallop whose paws are PLANTED during
+# their stance windows, so that the physics-based model (no-slip, foot height, ground-reaction forces) has a consistent problem.
+def _smoother(s):
+    s = np.clip(s, 0.0, 1.0)
+    return s * s * s * (10.0 - 15.0 * s + 6.0 * s * s)          # C2 step
+
+
+def gallop_trajectory(sk: abi.Skeleton, N: int, fps: float, rng: np.random.Generator, speed: float = 7.0, stride_hz: float = 3.0,
+                      stance_frames: int = 12, clearance: float = 0.05):
+    """q[N, nq] and stance[N, 4] (feet in skeleton.FEET order: HFL, HFR, HBL, HBR) of a rotary gallop along +x: the trunk moves on
+    smooth sinusoids, every paw stands still on the ground (z = 0) for `stance_frames` frames per stride -- touch-downs in the order
+    back-right, back-left, front-right, front-left, a quarter stride apart -- and swings forward on a C2 curve in between; the leg
+    angles follow by planar inverse kinematics (leg links are rotations of their body about its y axis, cheetah.py:71-72,101)."""
+    from .skeleton import FEET, FOOT_MARKERS, MARKERS
+    T = int(round(fps / stride_hz))                               # frames per stride
+    t = np.arange(N) / fps
+    w = 2 * math.pi * stride_hz
+    q = np.zeros((N, sk.nq))
+    ph = rng.uniform(0, 2 * math.pi, 8)
+    q[:, 0] = rng.uniform(0.0, 0.5) + speed * t
+    q[:, 1] = rng.uniform(-0.2, 0.2)
+    q[:, 2] = 0.60 + 0.012 * np.sin(w * t + ph[0])
+    for i in range(sk.n_links):
+        q[:, 3 + 3 * i + 2] = math.pi                             # '-x' aligned body running towards +x (acinoset_misc.py:454)
+    pitch = -0.10 + 0.04 * np.sin(w * t + ph[1])                 # nose down: the fore legs are shorter than the hind legs
+    q[:, dof("base", THETA)] = pitch
+    q[:, dof("bodyF", THETA)] = pitch - 0.06 - 0.05 * np.sin(w * t + ph[1] + 0.5)
+    q[:, dof("neck", THETA)] = q[:, dof("bodyF", THETA)] + 0.2 + 0.04 * np.sin(w * t + ph[2])
+    q[:, dof("tail0", THETA)] = pitch + 0.3 + 0.15 * np.sin(w * t + ph[3])
+    q[:, dof("tail1", THETA)] = q[:, dof("tail0", THETA)] + 0.15 * np.sin(w * t + ph[4])
+    lay = leg_layout(sk)
+    alpha = np.zeros((N, len(lay)))
+    stance = np.zeros((N, 4), np.int32)
+    off0 = int(rng.integers(0, T))
+    order = {"HBR": 0, "HBL": 1, "HFR": 2, "HFL": 3}               # touch-down order of the rotary gallop, a quarter stride apart
+    nl = sk.n_links
+    R = rot_zyx(q[..., 3:].reshape(N, nl, 3))
+    org = [None] * nl
+    for i in range(nl):
+        org[i] = q[:, 0:3] if sk.parent[i] < 0 else org[sk.parent[i]] + R[:, sk.parent[i]] @ np.array(sk.attach[i][:])
+    for k, foot in enumerate(FEET):
+        leg = foot[1:]                                            # FL, FR, BL, BR
+        iU, iL, iH = LINKS.index("U" + leg), LINKS.index("L" + leg), LINKS.index("H" + leg)
+        B = sk.parent[iU]
+        L1, L2 = abs(sk.attach[iL][2]), abs(sk.attach[iH][2])
+        L3 = abs(sk.marker_off[MARKERS.index(FOOT_MARKERS[k])][2])
+        back = leg[0] == "B"
+        hip = org[iU]                                             # [N, 3] world
+        td0 = off0 + order[foot] * (T // 4) - 2 * T                # first touch-down (before the clip starts)
+        # paw target in the world, frame by frame
+        tgt = np.zeros((N, 3))
+        hx = lambda fr: hip[0, 0] + speed * (fr - 0.0) / fps + (hip[:, 0] - (hip[0, 0] + speed * t)).mean()   # hip x on the mean line
+        for n in range(N):
+            j = (n - td0) // T                                    # stride index
+            td = td0 + j * T
+            xc = hx(td + 0.5 * (stance_frames - 1))                # planted under the hip at mid-stance
+            if n - td < stance_frames:
+                tgt[n] = (xc, hip[n, 1], 0.0); stance[n, k] = 1
+            else:
+                s = (n - (td + stance_frames - 1)) / float(T - stance_frames + 1)
+                xn = hx(td + T + 0.5 * (stance_frames - 1))
+                tgt[n] = (xc + (xn - xc) * _smoother(s), hip[n, 1], clearance * 64.0 * s**3 * (1 - s)**3)
+        d = np.einsum("nji,nj->ni", R[:, B], tgt - hip)             # body frame
+        dx, dz = d[:, 0], d[:, 2]
+        # three links, two equations: the thigh keeps a fixed angle A* to the hip -> paw line and the hock folds against the calf
+        # (delta = hock - calf) as the leg shortens, inside the joint ranges of cheetah.py:345-352
+        Astar = 0.7 if back else 0.9
+        D = np.minimum(np.hypot(dx, dz), 0.98 * (L1 + L2 + L3))
+        Lr = np.sqrt(L1 * L1 + D * D - 2 * L1 * D * math.cos(Astar))
+        Lr = np.clip(Lr, abs(L2 - L3) + 0.01, L2 + L3 - 0.005)
+        delta = np.arccos(np.clip((Lr * Lr - L2 * L2 - L3 * L3) / (2 * L2 * L3), -1, 1)) * (1.0 if back else -1.0)
+        beta = np.arctan2(L3 * np.sin(delta), L2 + L3 * np.cos(delta))
+        gam = np.arctan2(-dx, -dz)
+        A = np.arccos(np.clip((L1 * L1 + D * D - Lr * Lr) / (2 * L1 * D), -1, 1))
+        a1 = gam + A if back else gam - A                          # knee forward for the hind legs, backward for the fore legs
+        rx = -D * np.sin(gam) + L1 * np.sin(a1); rz = -D * np.cos(gam) + L1 * np.cos(a1)
+        a2 = np.arctan2(-rx, -rz)
+        for r, (c, Bk) in enumerate(lay):
+            if c == iU:
+                alpha[:, r] = a1
+            elif c == iL:
+                alpha[:, r] = a2 - beta
+            elif c == iH:
+                alpha[:, r] = a2 - beta + delta
+    q = legs_from_alpha(sk, q, alpha)
+    q = project_dependents_numpy_hooke(sk, q)
+    return q, stance
+
+
+def project_dependents_numpy_hooke(sk: abi.Skeleton, q: np.ndarray) -> np.ndarray:
+    """phi of the hooke children (tails) from their joint equality, everything else untouched"""
+    qh = project_dependents_numpy(sk, q)
+    q = q.copy()
+    for j in range(sk.n_joints):
+        if sk.joint_kind[j] == abi.JOINT_HOOKE_YZ:
+            c = sk.joint_child[j]
+            q[..., 3 + 3 * c] = qh[..., 3 + 3 * c]
+    return q
+
+
+def make_gallop_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0, seed: int = 4321, noise_px: float = 2.0,
+                      outlier_frac: float = 0.10, init_noise: float = 0.02, dlc_thresh: float = 0.5, speed: float = 7.0):
+    """config-4 sequences: q_true, q_init (truth + noise on the independent coordinates: the physics-based solve is warm-started
+    from a kinematic solution, acinoset_opt.py:739-777), meas, weight as make_batch, and stance [B, N, 4]."""
+    C, L, nq = len(cams), sk.n_markers, sk.nq
+    out = dict(q_true=np.empty((B, N, nq)), q_init=np.empty((B, N, nq)), meas=np.empty((B, N, C, L, 2)), weight=np.empty((B, N, C, L)),
+               stance=np.zeros((B, N, 4), np.int32))
+    sigma = measurement_sigma(L, False)
+    ind = independent_dofs(sk)
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        qt, st = gallop_trajectory(sk, N, fps, rng, speed=speed)
+        out["q_true"][b] = qt; out["stance"][b] = st
+        pos, _ = fk_numpy(sk, qt)
+        for c in range(C):
+            uv, z = project_numpy(cams[c], pos)
+            uv = uv + rng.normal(0, noise_px, uv.shape)
+            o = rng.random((N, L)) < outlier_frac
+            uv[o] = np.stack([rng.uniform(0, IMG_W, o.sum()), rng.uniform(0, IMG_H, o.sum())], axis=-1)
+            lik = rng.random((N, L))
+            vis = (z > 0.1) & (uv[..., 0] >= 0) & (uv[..., 0] < IMG_W) & (uv[..., 1] >= 0) & (uv[..., 1] < IMG_H)
+            uv[~vis] = 0.0
+            out["meas"][b, :, c] = uv
+            out["weight"][b, :, c] = np.where((lik > dlc_thresh) & vis, 1.0 / sigma[None, :], 0.0)
+        qi = qt.copy()
+        qi[:, ind] += rng.normal(0, init_noise, (N, len(ind))) * np.where(np.arange(len(ind)) < 3, 0.5, 1.0)
+        out["q_init"][b] = qi
+    out["meas"] = np.ascontiguousarray(out["meas"]); out["weight"] = np.ascontiguousarray(out["weight"])
+    return out

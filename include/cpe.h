@@ -286,6 +286,88 @@ typedef struct cpe_dyn_options {
 cpe_status cpe_eom_residual(cpe_handle* h, const cpe_dyn_options* opt, int32_t B, int32_t N, const double* q, const double* dq,
                             const double* ddq, const double* tau, const double* lambda, const double* grf, double* residual);
 
+/* ---- physics-based trajectory model (config 4: estimate_kinetics, acinoset_opt.py:693-963) -------------------
+ * The reference adds to the kinematic NLP, per node: 22 joint torques tau, 26 joint constraint forces lambda (`Fr`), four feet x
+ * (GRFz + 4 non-negative friction components), 54 slack_eom, and the equality
+ *     rows(q, q', q'') = B_grf + B_tau + (dc/dq)^T lambda + slack            (forces in body weights M g, cpe_eom_residual above)
+ * with the cost (acinoset_opt.py:905-921)
+ *     1e-3 ( measurement + GMM pose + sum tau^2 + 0.1 fps^-2 sum (fps^2 (pose[n+2] - 2 pose[n+1] + pose[n]))^2 + 10e3 sum slack^2 )
+ * -- no constant-acceleration term, no autoregressive prior -- and the contact schedule of prescribe_contact_order
+ * (acinoset_misc.py:1140-1167) + the no-slip rule (acinoset_opt.py:783-806): outside stance the foot force is fixed to 0; in stance
+ * GRFz >= grfz_min, |foot height| <= foot_height_tol, foot xy speed components <= slip_max; always 0 <= GRF <= force_max and
+ * friction * GRFz >= sum_k GRFxy_k.
+ *
+ * Statement solved here: slack is eliminated (it IS the residual e_n of the equality), the per-node forces
+ * f_n = (tau, lambda, net foot force (z, x, y) of every stance foot) enter e_n linearly and are minimised out exactly per node
+ * (a convex piecewise-quadratic problem, semismooth Newton), and the trajectory is found by the same Levenberg-Marquardt /
+ * block-banded Cholesky as cpe_solve on  V_n(u_n, u_n-1, u_n-2) = min_f [ w_slack |e_n|^2 + w_torque |tau|^2 + ... ]  (n >= 2: q'_0
+ * and q''_0 are free in the implicit-Euler collocation, so nodes 0 and 1 carry no dynamics), whose Gauss-Newton blocks are the
+ * Schur complements of the force unknowns.  The reference's four non-negative friction components enter only through their
+ * differences; the cost-neutral face is resolved by x+ x- = 0 (the minimum-norm point), i.e. net forces with |Fx| + |Fy| <= mu Fz.
+ * Inequalities: augmented Lagrangian (multipliers updated with the angle bounds').  slack_bound is verified at the solution
+ * (stats.max_slack), not enforced during the iteration.  motion_w of the handle's skeleton must be all zero.
+ * Versus the reference's `.robot` equations of motion this model is "parity unpinned" (SURVEY 8c-8): the pins are the numerical
+ * Lagrangian and virtual work (tests/test_grf.py). */
+#define CPE_MAX_MOTORS 32
+#define CPE_KIN_MAXLAT (CPE_MAX_MOTORS + 2 * CPE_MAX_JOINTS + 12)    /* latent forces per node: tau | lambda | (z, x, y) per foot */
+typedef struct cpe_kinetic_options {
+    cpe_dyn_options dyn;      /* gravity, link inertias, feet (markers at the hock bottoms), motors                              */
+    double w_slack;           /* 1e4 = `10e3 * slack_cost`            (acinoset_opt.py:921)                                      */
+    double w_torque;          /* 1                                    (torque_squared_penalty, :915)                             */
+    double w_smooth;          /* 0.1 / fps^2                          (:919-920), on |fps^2 * second difference of the markers|^2 */
+    double friction;          /* 0.8                                  (:506)                                                     */
+    double force_max;         /* 5                                    (:494-497)                                                 */
+    double grfz_min;          /* 0.01                                 (acinoset_misc.py:1144)                                    */
+    double foot_height_tol;   /* 0.1; 0.03 for the kinetic dataset    (acinoset_opt.py:780)                                      */
+    double foot_height_min;   /* 0: lower bound of `foot_height` outside stance (variable bound inside the absent pe.foot: unpinned); <= -1e9 disables */
+    double ground_height;     /* Foot3D.ground_plane_height           (:500)                                                     */
+    double slip_max;          /* 1: `gamma <= 1` in stance            (:803-806); <= 0 disables                                  */
+    double slack_bound;       /* 2: bound_eom_error                   (run_dataset.py:984)                                       */
+    double reg_force;         /* Tikhonov weight on lambda and the foot forces (1e-4): picks the minimum-norm point of a face the reference leaves open */
+    double kappa_force, kappa_height, kappa_slip;     /* augmented-Lagrangian penalties (1e5, 1e6, 1e2)                          */
+    double fd_step;           /* central-difference step in the reduced coordinates (1e-6)                                       */
+    double lm_damping;        /* > 0: Levenberg damping lambda * lm_damping * I on the coordinates instead of Marquardt's lambda * diag(H) */
+    double lm_force_damping;  /* the node forces are eliminated from (H_ff + lambda * lm_force_damping * diag(H_ff)): the trust region
+                               * also acts in FORCE space, where the walls of this problem (force bounds, friction polyhedron) are */
+    int32_t inner_iterations; /* cap on the per-node Newton iterations for the forces (30)                                       */
+    int32_t _pad;
+} cpe_kinetic_options;
+
+typedef struct cpe_kinetic_stats {
+    double cost_torque;       /* sum tau^2                      estimator.costs["torque"]    (acinoset_opt.py:922-928)           */
+    double cost_energy;       /* sum (fps^2 second difference)^2               ["energy"]                                        */
+    double cost_eom;          /* sum slack^2                                   ["eom_error"]                                     */
+    double max_slack;         /* largest |slack_eom| component (body weights), to hold against slack_bound                       */
+    double max_base_rows;     /* largest |rows 0-2 - forces| / (M g): the reference's stored solutions have <= 8e-5 */
+    double max_violation;     /* largest violated force / height / slip inequality at the solution                               */
+    int32_t inner_max;        /* largest Newton iteration count of a node in the last evaluation                                 */
+    int32_t _pad;
+} cpe_kinetic_stats;
+
+/* the reference's values for a given frame rate and data set (kinetic_dataset: foot_height_tol 0.03) */
+void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kinetic_dataset);
+
+/* Device pointers.  q_init [B][N][nq] = the kinematic solution (init_prev_kinematic_solution, acinoset_opt.py:739-777);
+ * stance int32 [B][N][n_feet] (1 = the foot is inside a contact window of autogen-contact.json, :783-812);
+ * outputs as cpe_solve plus tau [B][N][n_motors], lambda [B][N][n_constraints], grf [B][N][n_feet][5] = (z, +x, +y, -x, -y),
+ * slack [B][N][nq] (all zero at nodes 0 and 1); stats / kstats [B] are HOST pointers (kstats may be NULL).
+ * cpe_stats.cost_model carries w_torque * torque + w_smooth * energy + w_slack * eom (the reference's "motion prior + slack" part),
+ * cpe_stats.cost the whole objective times cost_scale. */
+cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                             const double* weight, const int32_t* stance, double* q, double* dq, double* ddq, double* positions,
+                             double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                             cpe_kinetic_stats* kstats);
+
+/* diagnostic building block of cpe_solve_kinetic (as cpe_eval_normal is of cpe_solve): ONE evaluation of the physics terms of every node at
+ * Euler q, multipliers zero, forces from a cold start -- what ASL hands IPOPT per node for the constraints of make_pyomo_model(include_eom_slack=True)
+ * (acinoset_opt.py:510-514) after the node forces are minimised out.  Device pointers, each may be NULL: f [B][N][64] node forces (tau | lambda |
+ * (z, x, y) per foot), stat [B][N][8] = (sum slack^2, sum tau^2, regularised norm, smoothing energy, multiplier terms, max |slack|, max |base rows|,
+ * max violation), g [B][N][84] gradient with respect to the coordinates of frames n, n-1, n-2, Huu [B][N][84][84], Hfu [B][N][64][84], Hff [B][N][64][64]
+ * (rows = free node forces in meta's order), meta int32 [B][N][65] = (count, indices). */
+cpe_status cpe_eval_kinetic_nodes(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q, const double* meas,
+                                  const double* weight, const int32_t* stance, double* f, double* stat, double* g, double* Huu, double* Hfu,
+                                  double* Hff, int32_t* meta);
+
 /* forward kinematics only (get_pose_state / get_com, acinoset_misc.py:1581-1659, :722-742); device ptrs */
 cpe_status cpe_forward_kinematics(cpe_handle* h, int32_t B, int32_t N, const double* q,
                                   double* positions /*[B][N][L][3]*/, double* com /*[B][N][3] or NULL*/);

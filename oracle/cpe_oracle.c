@@ -476,8 +476,10 @@ double cpo_gmm_cost(const cpe_priors* pr, const double* x22, double* grad) { ret
  * (real runs swing limbs through +-90 deg of pitch: tests/golden/fk_csv_pin.npz).  alpha_c sits at the
  * position of theta_c in the coordinate vector.  State of one frame: st[nq + nrev] = Euler q (54, kept
  * consistent by state_sync) followed by the nrev leg angles alpha. */
+struct kin_s;
 typedef struct {
     const cpe_skeleton* s; const cpe_camera* cams; int C; const cpe_options* o; const cpe_priors* pr;
+    struct kin_s* kin;            /* physics-based model (cpo_solve_kinetic), NULL for the kinematic models */
     int nq, nu, indep[CPE_MAX_NQ], dep[CPE_MAX_NQ], u_of_q[CPE_MAX_NQ];
     int nrev, ns;                 /* revolute (leg) links, state size nq + nrev */
     int rev_joint[CPE_MAX_JOINTS];/* joint index of revolute r */
@@ -486,7 +488,7 @@ typedef struct {
 } ctx_t;
 
 static void ctx_init(ctx_t* x, const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr) {
-    x->s = s; x->cams = cams; x->C = C; x->o = o; x->pr = pr; x->nq = NQ(s);
+    x->s = s; x->cams = cams; x->C = C; x->o = o; x->pr = pr; x->nq = NQ(s); x->kin = NULL;
     x->nu = cpo_split_dofs(s, x->indep, x->dep);
     for (int p = 0; p < x->nq; p++) x->u_of_q[p] = -1;
     for (int k = 0; k < x->nu; k++) { x->u_of_q[x->indep[k]] = k; x->rev_of_u[k] = -1; }
@@ -717,6 +719,11 @@ static void band_solve(int n, int kd, const double* ab, double* x) {
  * and, if g != NULL, gradient g[N*nu] and band matrix ab (without damping). */
 typedef struct { double meas, model, pose, motion, bound, total, maxviol; } costs_t;
 
+void cpo_eom_rows(const cpe_skeleton* s, const cpe_eom_options* o, const double* q, const double* dq, const double* ddq, double* E);
+void cpo_dyn_forces(const cpe_skeleton* s, const cpe_dyn_options* o, const double* q, const double* tau, const double* lam,
+                    const double* grf, double* Q);
+#include "cpe_oracle_kinetic.inc"
+
 static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states, synced in place */, const double* meas, const double* weight,
                      const double* mu /* [N][nb][2] or NULL */, costs_t* ct, double* g, double* ab) {
     const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, ns = x->ns, L = s->n_markers, C = x->C;
@@ -823,6 +830,7 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
         free(xs); if (Xp) free(Xp); if (Ku) free(Ku);
     }
 #undef Q
+    if (x->kin) kin_seq_terms(x, N, kd, st, ct, g, ab);
     ct->total = ct->meas + ct->model + ct->pose + ct->motion + ct->bound;
     if (gB) free(gB);
     if (Zall) free(Zall);
@@ -830,11 +838,12 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
 
 /* Levenberg-Marquardt over the whole trajectory in reduced coordinates (stands where IPOPT is called,
  * acinoset_opt.py:611-617).  Same algorithm as the HIP product (DESIGN.md "Solver"). */
-cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
-                     const cpe_priors* pr, int N, const double* q_init, const double* meas,
-                     const double* weight, double* q, double* dq, double* ddq, double* positions,
-                     double* meas_err, cpe_stats* st) {
+static cpe_status solve_impl(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
+                             const cpe_priors* pr, int N, const double* q_init, const double* meas,
+                             const double* weight, double* q, double* dq, double* ddq, double* positions,
+                             double* meas_err, cpe_stats* st, kin_t* K) {
     ctx_t x; ctx_init(&x, s, cams, C, o, pr);
+    x.kin = K;
     int nq = x.nq, nu = x.nu, ns = x.ns, L = s->n_markers;
     int bw = 3; if (pr && pr->lr_window > bw) bw = pr->lr_window;
     int kd = (bw + 1) * nu - 1, n_tot = N * nu;
@@ -843,6 +852,8 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     double* g = (double*)malloc(sizeof(double) * n_tot);
     double* ab = (double*)malloc(sizeof(double) * (size_t)n_tot * (kd + 1));
     double* abf = (double*)malloc(sizeof(double) * (size_t)n_tot * (kd + 1));
+    double* abm = K ? (double*)malloc(sizeof(double) * (size_t)n_tot * (kd + 1)) : NULL;
+    const double* abp = K ? abm : ab;                   /* matrix of the quadratic model whose decrease is `pred` */
     double* dl = (double*)malloc(sizeof(double) * n_tot);
     for (int n = 0; n < N; n++) state_from_q(&x, q_init + (size_t)n * nq, qc + (size_t)n * ns);
     costs_t cc, ctr;
@@ -857,7 +868,12 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
         int inner_done = 0;
         /* (H + lam diag(H)) dl = -g */
         memcpy(abf, ab, sizeof(double) * (size_t)n_tot * (kd + 1));
-        for (int i = 0; i < n_tot; i++) { double d = abf[(size_t)i * (kd + 1)]; abf[(size_t)i * (kd + 1)] = d + lam * (d > 1e-12 ? d : 1e-12); }
+        if (K) {            /* physics terms: Schur complement of the node forces, damped in force space with the same lambda */
+            kin_add_schur(&x, N, kd, lam * K->ko->lm_force_damping, abf);
+            memcpy(abm, abf, sizeof(double) * (size_t)n_tot * (kd + 1));        /* the model matrix of this iteration (for pred) */
+        }
+        const double dabs = K ? K->ko->lm_damping : 0.0;        /* > 0: Levenberg damping lambda * dabs * I (include/cpe.h, lm_damping) */
+        for (int i = 0; i < n_tot; i++) { double d = abf[(size_t)i * (kd + 1)]; abf[(size_t)i * (kd + 1)] = d + lam * (dabs > 0 ? dabs : (d > 1e-12 ? d : 1e-12)); }
         if (band_cholesky(n_tot, kd, abf)) { lam *= 10; if (lam > 1e12) { status = CPE_NUMERICAL; } continue; }
         for (int i = 0; i < n_tot; i++) dl[i] = -g[i];
         band_solve(n_tot, kd, abf, dl);
@@ -867,21 +883,24 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
             gd += g[i] * dl[i];
             double hv = 0;
             int k0 = i - kd > 0 ? i - kd : 0, k1 = i + kd < n_tot - 1 ? i + kd : n_tot - 1;
-            for (int k = k0; k <= i; k++) hv += ab[(size_t)i * (kd + 1) + (i - k)] * dl[k];
-            for (int k = i + 1; k <= k1; k++) hv += ab[(size_t)k * (kd + 1) + (k - i)] * dl[k];
+            for (int k = k0; k <= i; k++) hv += abp[(size_t)i * (kd + 1) + (i - k)] * dl[k];
+            for (int k = i + 1; k <= k1; k++) hv += abp[(size_t)k * (kd + 1) + (k - i)] * dl[k];
             dHd += dl[i] * hv;
             if (fabs(dl[i]) > maxstep) maxstep = fabs(dl[i]);
         }
         double pred = -gd - 0.5 * dHd;
         memcpy(qt, qc, sizeof(double) * N * ns);
         for (int n = 0; n < N; n++) for (int k = 0; k < nu; k++) state_add(&x, qt + (size_t)n * ns, k, dl[n * nu + k]);
+        if (K) K->write_try = 1;
         seq_eval(&x, N, kd, qt, meas, weight, mu, &ctr, NULL, NULL);
+        if (K) K->write_try = 0;
         double act = cc.total - ctr.total;
         double gain = pred > 0 ? act / pred : -1;
         if (getenv("CPO_DEBUG")) fprintf(stderr, "it %3d cost %.10f trial %.10f pred %.3e act %.3e gain %.3f lam %.2e step %.2e viol %.2e\n", it, cc.total, ctr.total, pred, act, gain, lam, maxstep, cc.maxviol);
         if (isfinite(ctr.total) && act > 0 && gain > 1e-4) {
             double rel = act / (fabs(cc.total) + 1e-30);
             memcpy(qc, qt, sizeof(double) * N * ns);
+            if (K) { double* t_ = K->f_cur; K->f_cur = K->f_try; K->f_try = t_; }      /* the trial's node forces become the warm start */
             seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
             double f = 1 - (2 * gain - 1) * (2 * gain - 1) * (2 * gain - 1);
             lam *= f > 1.0 / 3 ? f : 1.0 / 3; nu_f = NU0;
@@ -903,12 +922,14 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
                         double t_up = m2[0] + o->bound_penalty * (v - s->bound_up[b]), t_lo = m2[1] + o->bound_penalty * (s->bound_lo[b] - v);
                         m2[0] = t_up > 0 ? t_up : 0; m2[1] = t_lo > 0 ? t_lo : 0;
                     }
+                if (K) K->update_mu = 1;          /* force / height / slip multipliers: updated inside the evaluation, node by node */
                 seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
                 if (lam > 1e-3) lam = 1e-3;
                 nu_f = NU0;
             } else status = CPE_OK;
         }
     }
+    if (K) seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, NULL, NULL);      /* node forces and statistics of the FINAL iterate (the last evaluation may have been a rejected trial) */
     /* outputs as CheetahEstimator.save writes them (acinoset_opt.py:289-361) */
     for (int n = 0; n < N; n++) memcpy(q + (size_t)n * nq, qc + (size_t)n * ns, sizeof(double) * nq);
     if (dq && ddq) cpo_derivatives(nq, N, o->h, q, dq, ddq);
@@ -932,8 +953,137 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
         st->cost_meas = cc.meas; st->cost_model = cc.model; st->cost_pose = cc.pose; st->cost_motion = cc.motion;
         st->cost = o->cost_scale * (cc.meas + cc.model + cc.pose + cc.motion);
     }
-    free(qc); free(qt); free(g); free(ab); free(abf); free(dl); free(mu);
+    free(qc); free(qt); free(g); free(ab); free(abf); free(dl); free(mu); if (abm) free(abm);
     return status;
+}
+
+cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
+                     const cpe_priors* pr, int N, const double* q_init, const double* meas,
+                     const double* weight, double* q, double* dq, double* ddq, double* positions,
+                     double* meas_err, cpe_stats* st) {
+    return solve_impl(s, cams, C, o, pr, N, q_init, meas, weight, q, dq, ddq, positions, meas_err, st, NULL);
+}
+
+void cpo_default_kinetic_options(cpe_kinetic_options* o, double fps, int kinetic_dataset) {
+    /* o->dyn (inertias, feet, motors) is the caller's */
+    o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
+    o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->slack_bound = 2.0;
+    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_damping = 0.0; o->lm_force_damping = 1.0; o->inner_iterations = 30; o->_pad = 0;
+}
+
+/* objective of the physics-based model at a point (multipliers zero), its reduced gradient and, optionally, the band matrix:
+ * for finite-difference checks of kin_term (tests) */
+double cpo_kinetic_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                             const cpe_kinetic_options* ko, int N, double* q, const double* meas, const double* weight, const int32_t* stance,
+                             double* g /*[N*nu] or NULL*/, double* Hband /*[N*nu][4 nu] or NULL*/, double* terms /*[8] or NULL*/) {
+    ctx_t x; ctx_init(&x, s, cams, C, o, pr);
+    kin_t K; memset(&K, 0, sizeof(K));
+    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h;
+    for (int j = 0; j < s->n_joints; j++) K.nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
+    K.nlat = K.nm + K.nc + 3 * K.nf;
+    double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
+    K.Mg = M * ko->dyn.eom.gravity;
+    K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
+    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
+    K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
+    K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
+    x.kin = &K;
+    int kd = 4 * x.nu - 1;
+    costs_t ct;
+    double* st = (double*)malloc(sizeof(double) * (size_t)N * x.ns);
+    for (int n = 0; n < N; n++) state_from_q(&x, q + (size_t)n * x.nq, st + (size_t)n * x.ns);
+    double* ab = g ? (Hband ? Hband : (double*)malloc(sizeof(double) * (size_t)N * x.nu * (kd + 1))) : NULL;
+    seq_eval(&x, N, kd, st, meas, weight, NULL, &ct, g, ab);
+    for (int n = 0; n < N; n++) memcpy(q + (size_t)n * x.nq, st + (size_t)n * x.ns, sizeof(double) * x.nq);
+    if (terms) { terms[0] = ct.meas; terms[1] = ct.model; terms[2] = ct.pose; terms[3] = ct.bound; terms[4] = K.torque; terms[5] = K.energy; terms[6] = K.eom; terms[7] = K.al; }
+    if (g && ab) kin_add_schur(&x, N, kd, 0.0, ab);           /* exact variable-projection Gauss-Newton matrix */
+    if (g && !Hband) free(ab);
+    free(st); free(K.f_cur); free(K.f_try); free(K.mu); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
+    return ct.total;
+}
+
+/* per-node quantities of one evaluation of the physics terms (multipliers zero, cold start), in cpe_eval_kinetic_nodes' layout:
+ * f [N][64], stat [N][8], g [N][84], Huu [N][84][84], Hfu [N][64][84], Hff [N][64][64], meta [N][65] */
+void cpo_kinetic_nodes(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_kinetic_options* ko, int N,
+                       const double* q, const int32_t* stance, double* f, double* stat, double* g, double* Huu, double* Hfu, double* Hff, int32_t* meta) {
+    ctx_t x; ctx_init(&x, s, cams, C, o, NULL);
+    kin_t K; memset(&K, 0, sizeof(K));
+    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h;
+    for (int j = 0; j < s->n_joints; j++) K.nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
+    K.nlat = K.nm + K.nc + 3 * K.nf;
+    double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
+    K.Mg = M * ko->dyn.eom.gravity;
+    K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
+    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
+    K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
+    K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
+    x.kin = &K;
+    double* st = (double*)malloc(sizeof(double) * (size_t)N * x.ns);
+    for (int n = 0; n < N; n++) state_from_q(&x, q + (size_t)n * x.nq, st + (size_t)n * x.ns);
+    int nc3 = KIN_NC3;
+    double* gT = (double*)malloc(sizeof(double) * nc3); double* HT = (double*)malloc(sizeof(double) * nc3 * nc3);
+    for (int n = 0; n < N; n++) {
+        kin_node_t R; memset(&R, 0, sizeof(R));
+        memset(gT, 0, sizeof(double) * nc3);
+        int na = 0, idx[CPE_KIN_MAXLAT];
+        if (n >= 2) {
+            kin_term(&x, &K, n, st + (size_t)n * x.ns, st + (size_t)(n - 1) * x.ns, st + (size_t)(n - 2) * x.ns, gT, HT, &R);
+            na = K.pna[n];
+            for (int m = 0; m < K.nm + K.nc; m++) idx[m] = m;
+            int a = K.nm + K.nc;
+            for (int k = 0; k < K.nf; k++) if (stance[(size_t)n * K.nf + k]) for (int d = 0; d < 3; d++) idx[a++] = K.nm + K.nc + 3 * k + d;
+        }
+        if (f) { for (int i = 0; i < 64; i++) f[(size_t)n * 64 + i] = i < K.nlat && n >= 2 ? K.f_cur[(size_t)n * K.nlat + i] : 0.0; }
+        if (stat) { double* d = stat + (size_t)n * 8; d[0] = R.eom; d[1] = R.torque; d[2] = R.reg; d[3] = R.energy; d[4] = R.al; d[5] = R.max_slack; d[6] = R.max_base; d[7] = R.max_viol; }
+        if (g) memcpy(g + (size_t)n * nc3, gT, sizeof(double) * nc3);
+        if (meta) { meta[(size_t)n * 65] = na; for (int i = 0; i < na; i++) meta[(size_t)n * 65 + 1 + i] = idx[i]; }
+        if (n < 2) continue;
+        if (Huu) memcpy(Huu + (size_t)n * nc3 * nc3, K.pHuu + (size_t)n * nc3 * nc3, sizeof(double) * nc3 * nc3);
+        if (Hfu) for (int i = 0; i < na; i++) memcpy(Hfu + ((size_t)n * 64 + i) * nc3, K.pHfu + (size_t)n * CPE_KIN_MAXLAT * nc3 + (size_t)i * nc3, sizeof(double) * nc3);
+        if (Hff) for (int i = 0; i < na; i++) for (int j = 0; j < na; j++) Hff[((size_t)n * 64 + i) * 64 + j] = K.pHff[(size_t)n * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT + (size_t)i * na + j];
+    }
+    free(gT); free(HT); free(st); free(K.f_cur); free(K.f_try); free(K.mu); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
+}
+
+/* physics-based trajectory model: include/cpe.h, cpe_solve_kinetic (estimate_kinetics, acinoset_opt.py:693-963) */
+cpe_status cpo_solve_kinetic(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                             const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
+                             const int32_t* stance, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                             double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
+    int nq = NQ(s);
+    for (int p = 0; p < nq; p++) if (s->motion_w[p] != 0.0) return CPE_BAD_ARG;      /* the physics replaces the constant-acceleration cost */
+    kin_t K; memset(&K, 0, sizeof(K));
+    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h;
+    for (int j = 0; j < s->n_joints; j++) K.nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
+    K.nlat = K.nm + K.nc + 3 * K.nf;
+    if (K.nlat > CPE_KIN_MAXLAT) return CPE_BAD_ARG;
+    double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
+    K.Mg = M * ko->dyn.eom.gravity;
+    K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
+    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
+    K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
+    K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
+    cpe_status rc = solve_impl(s, cams, C, o, pr, N, q_init, meas, weight, q, dq, ddq, positions, meas_err, st, &K);
+    /* node forces of the final iterate; slack = the residual of the equations of motion there */
+    ctx_t x; ctx_init(&x, s, cams, C, o, pr);
+    for (int n = 0; n < N; n++) {
+        const double* f = K.f_cur + (size_t)n * K.nlat;
+        double tq[CPE_MAX_MOTORS], lN[2 * CPE_MAX_JOINTS], g5[20], rho[KIN_MAXROWS];
+        kin_split_forces(&K, f, tq, lN, g5);
+        if (tau) for (int m = 0; m < K.nm; m++) tau[(size_t)n * K.nm + m] = n >= 2 ? tq[m] : 0.0;
+        if (lam) for (int r = 0; r < K.nc; r++) lam[(size_t)n * K.nc + r] = n >= 2 ? f[K.nm + r] : 0.0;
+        if (grf) for (int k = 0; k < 5 * K.nf; k++) grf[(size_t)n * 5 * K.nf + k] = n >= 2 ? g5[k] : 0.0;
+        if (slack) {
+            if (n >= 2) { kin_rho(&x, &K, q + (size_t)n * nq, q + (size_t)(n - 1) * nq, q + (size_t)(n - 2) * nq, f, rho); memcpy(slack + (size_t)n * nq, rho, sizeof(double) * nq); }
+            else memset(slack + (size_t)n * nq, 0, sizeof(double) * nq);
+        }
+    }
+    if (kst) {
+        kst->cost_torque = K.torque; kst->cost_energy = K.energy; kst->cost_eom = K.eom; kst->max_slack = K.max_slack;
+        kst->max_base_rows = K.max_base; kst->max_violation = K.max_viol; kst->inner_max = K.inner_max; kst->_pad = 0;
+    }
+    free(K.f_cur); free(K.f_try); free(K.mu); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
+    return rc;
 }
 
 /* bench.py's multi-thread CPU solve leg: B independent sequences, one cpo_solve each, spread over OpenMP threads (the way a

@@ -96,6 +96,50 @@ def solve_batch(sk, cams, opts, q_init, meas, weight, threads=0, priors=None):
     return int(used), q, its
 
 
+def solve_kinetic(sk, cams, opts, priors, kopts, q_init, meas, weight, stance):
+    """physics-based trajectory model (cpo_solve_kinetic): one sequence, numpy in / out"""
+    q_init, meas, weight = _c(q_init), _c(meas), _c(weight)
+    stance = np.ascontiguousarray(stance, dtype=np.int32)
+    N, Cn, L = weight.shape
+    nq, nm, nf = sk.nq, kopts.dyn.n_motors, kopts.dyn.n_feet
+    nc = sum(2 if sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y else 1 for j in range(sk.n_joints))
+    q = np.empty((N, nq)); dq = np.empty((N, nq)); ddq = np.empty((N, nq))
+    pos = np.empty((N, L, 3)); me = np.empty((N, Cn, L, 2))
+    tau = np.empty((N, nm)); lam = np.empty((N, nc)); grf = np.empty((N, nf, 5)); slack = np.empty((N, nq))
+    st = abi.Stats(); ks = abi.KineticStats()
+    rc = lib().cpo_solve_kinetic(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, C.byref(kopts), N,
+                                 _p(q_init), _p(meas), _p(weight), stance.ctypes.data_as(C.POINTER(C.c_int32)), _p(q), _p(dq), _p(ddq), _p(pos), _p(me),
+                                 _p(tau), _p(lam), _p(grf), _p(slack), C.byref(st), C.byref(ks))
+    return dict(status=rc, q=q, dq=dq, ddq=ddq, positions=pos, meas_err=me, tau=tau, lam=lam, grf=grf, slack=slack, stats=st, kstats=ks)
+
+
+def kinetic_objective(sk, cams, opts, priors, kopts, q, meas, weight, stance, want_grad=True, want_band=False):
+    """(total, g [N, nu] or None, consistent q, terms[8], band or None) of the physics-based model's objective at q"""
+    q, meas, weight = _c(q).copy(), _c(meas), _c(weight)
+    stance = np.ascontiguousarray(stance, dtype=np.int32)
+    N, Cn, L = weight.shape
+    nu = 28
+    g = np.zeros((N, nu)) if want_grad else None
+    band = np.zeros((N * nu, 4 * nu)) if want_band else None
+    terms = np.zeros(8)
+    lib().cpo_kinetic_objective.restype = C.c_double
+    f = lib().cpo_kinetic_objective(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, C.byref(kopts), N,
+                                    _p(q), _p(meas), _p(weight), stance.ctypes.data_as(C.POINTER(C.c_int32)), _p(g), _p(band), _p(terms))
+    return float(f), g, q, terms, band
+
+
+def kinetic_nodes(sk, cams, opts, kopts, q, stance):
+    """per-node quantities of one evaluation of the physics terms, in cpe_eval_kinetic_nodes' layout (dict of arrays)"""
+    q = _c(q); stance = np.ascontiguousarray(stance, dtype=np.int32)
+    N = q.shape[0]
+    out = dict(f=np.zeros((N, 64)), stat=np.zeros((N, 8)), g=np.zeros((N, 84)), Huu=np.zeros((N, 84, 84)), Hfu=np.zeros((N, 64, 84)),
+               Hff=np.zeros((N, 64, 64)), meta=np.zeros((N, 65), dtype=np.int32))
+    lib().cpo_kinetic_nodes(C.byref(sk), cams, len(cams), C.byref(opts), C.byref(kopts), N, _p(q), stance.ctypes.data_as(C.POINTER(C.c_int32)),
+                            _p(out["f"]), _p(out["stat"]), _p(out["g"]), _p(out["Huu"]), _p(out["Hfu"]), _p(out["Hff"]),
+                            out["meta"].ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
 def markers_jac(sk, q):
     q = _c(q)
     pos = np.empty((sk.n_markers, 3))

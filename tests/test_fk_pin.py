@@ -22,10 +22,11 @@ def _rodrigues(r):
     return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
 
 
-def _cams():
+def _cams(Zp=None):
+    Zp = Z if Zp is None else Zp
     cams = (abi.Camera * 6)()
     for c in range(6):
-        p = Z["cams"][c]
+        p = Zp["cams"][c]
         cam = cams[c]
         cam.model = abi.CAM_FISHEYE
         cam.fx, cam.fy, cam.cx, cam.cy = p[0:4]
@@ -62,6 +63,35 @@ def test_oracle_fk_and_projection_reproduce_the_stored_2d_files(oracle):
                        ("r_front_knee", "r_front_ankle", p["front"]["calf"]["length"]), ("l_back_ankle", "l_back_paw", p["back"]["hock"]["length"])):
         dist = np.linalg.norm(pos[:, M[a]] - pos[:, M[b]], axis=1)
         assert np.abs(dist - Lref).max() < 1e-12
+
+
+ZJ = np.load(os.path.join(os.path.dirname(__file__), "golden", "fk_csv_pin_jules.npz"))
+
+
+def test_second_animal_and_recording_year(oracle):
+    """the same pin on another animal, another rig and another year -- data/test_set/2017_08_29/top/jules/run1_1/
+    fte_kinematic/cam{1..6}_fte.csv (30 frames x 6 cameras x 24 markers, 1920 x 1080 read-out, 90 fps), recovered by
+    `tools/pin_fk_from_csv.py 2017_08_29/top/jules/run1_1 fte_kinematic fk_csv_pin_jules.npz`: jules' link table of
+    cheetah_params.py + the FK chain + the marker offsets + the joint equalities + the fisheye model reproduce all 8 640 stored
+    numbers to < 1e-5 px (rms 4.7e-8 px)."""
+    sk = skeleton.build_skeleton(str(ZJ["animal"]), 24)
+    assert str(ZJ["animal"]) == "jules" and ZJ["uv"].shape == (30, 6, 24, 2) and not np.isnan(ZJ["uv"]).any()
+    cams = _cams(ZJ)
+    pos = oracle.markers(sk, ZJ["q"])
+    got = np.array([[[oracle.project(cams[c], pos[n, l]) for l in range(24)] for c in range(6)] for n in range(30)])
+    err = np.abs(got - ZJ["uv"])
+    assert err.max() < 1e-5 and np.sqrt((err ** 2).mean()) < 1e-6
+    assert max(np.abs(oracle.constraints(sk, x)).max() for x in ZJ["q"]) < 1e-12
+    pj = skeleton.load_params("jules")
+    M = {m: i for i, m in enumerate(skeleton.MARKERS)}
+    for a, b, Lref in (("spine", "tail_base", pj["body_B"]["length"]), ("spine", "neck_base", pj["body_F"]["length"]),
+                       ("r_back_knee", "r_back_ankle", pj["back"]["calf"]["length"]), ("l_front_ankle", "l_front_paw", pj["front"]["hock"]["length"])):
+        assert np.abs(np.linalg.norm(pos[:, M[a]] - pos[:, M[b]], axis=1) - Lref).max() < 1e-12
+    # and it is NOT the phantom table that fits: with phantom's link lengths the same angles miss by pixels
+    skp = skeleton.build_skeleton("phantom", 24)
+    posp = oracle.markers(skp, ZJ["q"])
+    gotp = np.array([[oracle.project(cams[0], posp[n, l]) for l in range(24)] for n in range(30)])
+    assert np.abs(gotp - ZJ["uv"][:, 0]).max() > 1.0
 
 
 def test_numpy_host_fk_agrees_on_the_recovered_angles():

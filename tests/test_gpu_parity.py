@@ -296,6 +296,12 @@ def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_
     meas = np.ascontiguousarray(Z["uv"][None])
     r, J, eps, cost = h.eval_resjac_host(q, meas, np.ones((1, 57, 6, 24)))
     assert np.abs(r).max() < 1e-4 and np.sqrt((r ** 2).mean()) < 5e-6
+    # second fixture: jules, 2017 rig (tests/test_fk_pin.py::test_second_animal_and_recording_year)
+    from test_fk_pin import ZJ
+    skj = skeleton.build_skeleton("jules", 24)
+    hj = gpu_handle_factory(skj, _cams(ZJ))
+    rj = hj.eval_resjac_host(ZJ["q"][None], np.ascontiguousarray(ZJ["uv"][None]), np.ones((1, 30, 6, 24)))[0]
+    assert np.abs(rj).max() < 1e-5 and np.sqrt((rj ** 2).mean()) < 1e-6
 
 
 def test_solve_on_the_real_run_matches_oracle(oracle, gpu_handle_factory):
