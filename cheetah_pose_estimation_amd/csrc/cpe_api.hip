@@ -852,7 +852,7 @@ void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kin
     // o->dyn (inertias, feet, motors) is the caller's
     o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
     o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->slack_bound = 2.0;
-    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_damping = 0.0; o->lm_force_damping = 1.0;
+    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 30.0;
     o->inner_iterations = 30; o->_pad = 0;
 }
 

@@ -238,6 +238,9 @@ class CheetahEstimator:
     result: Optional[dict] = None
     com_pos: Optional[np.ndarray] = None
     com_vel: Optional[np.ndarray] = None
+    enable_eom_slack: bool = True
+    bound_eom_error: Optional[Tuple[float, float]] = None
+    kinetic: Optional[dict] = None          # node forces of the last estimate_kinetics (tau, lam, grf, slack, stance)
 
     def get_objective_cost(self) -> float:
         return float(self.result["stats"][0].cost) if self.result else float("nan")
@@ -285,6 +288,36 @@ class CheetahEstimator:
         grfxy_est = {f: [[float(v) for v in row] for row in gxy[0, :, i]] for i, f in enumerate(feet)}
         return grfz_est, grfxy_est
 
+    def robot_data(self) -> dict:
+        """`cheetah.pickle` of a physics-based run: the layout `System3D.save_data_to_file` gives the reference's files (SURVEY 8b:
+        name, description, nfe, ncp, hm, hm0, links: [{name, is_base, mass, length, radius, q, dq, ddq, Fr, nodes}]): per link the
+        collocation variables, the joint constraint forces the link takes part in, and its nodes -- a motor (`Tc`) or a foot (`GRFz`,
+        `GRFxy`, `foot_height`).  The library that defines the exact field shapes is absent (physical_education): unpinned."""
+        sk, res, kin = self.skeleton, self.result, self.kinetic
+        q, dq, ddq = res["q"][0], res["dq"][0], res["ddq"][0]
+        N = q.shape[0]
+        p = skeleton.load_params(self.name)
+        groups = dict(skeleton.motor_groups())
+        links = []
+        for i, name in enumerate(skeleton.LINKS):
+            lp = skeleton._link_param(p, name)
+            sl = slice(0, 6) if i == 0 else slice(3 + 3 * i, 6 + 3 * i)
+            rows = [r for r, (par, ch) in enumerate(skeleton.constraint_rows(sk)) if i in (par, ch)]
+            nodes = []
+            for mname, cols in groups.items():
+                if mname.startswith(name + "_"):
+                    nodes.append(dict(name=mname, Tc=kin["tau"][:, cols]))
+            if name in skeleton.FEET:
+                k = skeleton.FEET.index(name)
+                mk = skeleton.MARKERS.index(skeleton.FOOT_MARKERS[k])
+                nodes.append(dict(name=f"{name}_foot", GRFz=kin["grf"][:, k, 0], GRFxy=kin["grf"][:, k, 1:5],
+                                  foot_height=res["positions"][0][:, mk, 2] - kin["ground_height"], stance=kin["stance"][:, k]))
+            links.append(dict(name=name, is_base=i == 0, meta=[], mass=lp["mass"], length=lp["length"], radius=lp["radius"],
+                              q=q[:, sl], dq=dq[:, sl], ddq=ddq[:, sl], Fr=kin["lam"][:, rows], nodes=nodes))
+        h = 1.0 / self.scene.fps
+        return dict(name=f"cheetah-{self.name}", description="Auto Save", repr="cheetah_pose_estimation_amd physics-based estimate",
+                    nfe=N, ncp=1, hm=np.full(N, h), hm0=h, slack_eom=kin["slack"], links=links)
+
     def save(self, out_dir: str, fname: str = "fte", out_dir_prefix: Optional[str] = None):
         """fte.pickle + cam*_fte.csv, acinoset_opt.py:278-373."""
         res, params, scene = self.result, self.params, self.scene
@@ -294,12 +327,19 @@ class CheetahEstimator:
             out_dir = os.path.join(params.data_dir, out_dir or "fte")
         os.makedirs(out_dir, exist_ok=True)
         q, dq, ddq = res["q"][0], res["dq"][0], res["ddq"][0]
+        tau = {}
+        if self.kinetic is not None:                                # {motor name: [N, components]} (acinoset_opt.py:317-324)
+            for name, cols in skeleton.motor_groups():
+                tau[name] = np.ascontiguousarray(self.kinetic["tau"][:, cols])
         output = dict(positions=res["positions"][0], x=self.relative_angles(q), dx=self.relative_angles(dq),
                       ddx=self.relative_angles(ddq), q=q, dq=dq, ddq=ddq, com_pos=self.com_pos, com_vel=self.com_vel,
-                      tau={}, meas_err=res["meas_err"][0][..., None], obj_cost=self.get_objective_cost(),
+                      tau=tau, meas_err=res["meas_err"][0][..., None], obj_cost=self.get_objective_cost(),
                       processing_time_s=self.opt_time_s, start_frame=params.start_frame)
         with open(os.path.join(out_dir, f"{fname}.pickle"), "wb") as f:
             pickle.dump(output, f)
+        if not self.kinematic_model and self.kinetic is not None:
+            with open(os.path.join(out_dir, "cheetah.pickle"), "wb") as f:      # robot.save_data_to_file (acinoset_opt.py:372-373)
+                pickle.dump(self.robot_data(), f)
         off = [0] * scene.n_cams
         if params.sync_offset is not None:
             for o in params.sync_offset:
@@ -337,8 +377,6 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
                     device: int = 0) -> CheetahEstimator:
     """Same signature and meaning as acinoset_opt.init_trajectory (acinoset_opt.py:413-536).  `solver_path`
     (the IPOPT binary of the reference) is accepted and ignored."""
-    if not kinematic_model:
-        raise NotImplementedError("the dynamic (kinetic) model -- SURVEY 8 rows a12/a13 -- is not built yet; pass kinematic_model=True")
     if shutter_delay_estimation or enable_ppm or hand_labeled_data:
         raise NotImplementedError("shutter delay / pairwise pseudo-measurements / hand labels are SURVEY 8f-4 (next)")
     if cheetah_name not in ("jules", "phantom", "shiraz", "arabia"):
@@ -372,7 +410,7 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
     meas, weight = build_measurements(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx, device=device)
     total_mass = sum(sk.mass[i] for i in range(sk.n_links))
     return CheetahEstimator(cheetah_name, data_path, params, scene, sk, scene_cameras(scene, kinetic_dataset), meas, weight,
-                            total_mass * 9.81, kinematic_model, tables, device)
+                            total_mass * 9.81, kinematic_model, tables, device, enable_eom_slack=enable_eom_slack, bound_eom_error=bound_eom_error)
 
 
 def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True, monocular_constraints: bool = False,
@@ -470,10 +508,105 @@ def determine_contacts(estimator: CheetahEstimator, monocular: bool = False, ver
     return contacts, by_height
 
 
-def estimate_kinetics(estimator, *args, **kwargs) -> bool:
-    raise NotImplementedError("physics-based model (acinoset_opt.py:693-963): SURVEY 8 row a12, not built yet")
+def stance_from_contacts(contact_json: dict, n_frames: int, first_frame: int) -> np.ndarray:
+    """contact windows [first, last, foot, label] of `autogen-contact.json` / metadata.json -> stance[N, 4] in skeleton.FEET order: frame
+    first - start_frame ... last - start_frame INCLUSIVE, as `contact_times` of acinoset_opt.py:787-798"""
+    start = contact_json["start_frame"]
+    st = np.zeros((n_frames, len(skeleton.FEET)), np.int32)
+    for k, foot in enumerate(skeleton.FEET):
+        for win in (contact_json["contacts"].get(f"{foot}_foot") or []):
+            a, b = int(win[0]) - start + (start - first_frame), int(win[1]) - start + (start - first_frame)
+            st[max(a, 0):max(min(b + 1, n_frames), 0), k] = 1
+    return st
+
+
+def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, auto: bool = True, use_2d_reprojections: bool = True,
+                      solver_output: bool = True, init_prev_kinematic_solution: bool = True, synthesised_grf: bool = False,
+                      no_slip: bool = True, joint_estimation: bool = False, fix_grf: bool = True, ground_constraint: bool = False,
+                      disable_pose_prior: bool = False, disable_motion_prior: bool = False, plot: bool = False, out_fname: str = "fte",
+                      out_dir_prefix: Optional[str] = None, options: Optional[abi.Options] = None,
+                      kinetic_options: Optional[abi.KineticOptions] = None) -> bool:
+    """Same signature and meaning as acinoset_opt.estimate_kinetics (acinoset_opt.py:693-708) for the branch its drivers run for the
+    physics-based reconstruction (`joint_estimation=True`, run_dataset.py:1198-1229): torques, joint constraint forces, ground-reaction
+    forces and the trajectory are estimated together, warm-started from the kinematic solution on disk, with the contact windows of
+    `grf/autogen-contact.json` (auto) or `metadata.json`.  The whole NLP runs on the GPU (cpe_solve_kinetic).  `init_torques` has no
+    effect here: the torques are minimised out exactly at every evaluation, so they need no starting value.  Branches that prescribe
+    the forces from a file (`joint_estimation=False`: synthesised or per-frame-fitted GRF held fixed) are not built."""
+    est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
+    if est.kinematic_model:
+        raise AssertionError("Dynamic model of the cheetah is required.")          # the reference asserts hasattr(model, 'eom_f')
+    if not joint_estimation:
+        raise NotImplementedError("estimate_kinetics with prescribed ground-reaction forces (joint_estimation=False) is not built; "
+                                  "the physics-based reconstruction of run_dataset.py uses joint_estimation=True")
+    if not use_2d_reprojections:
+        raise NotImplementedError("the 3D kinematic cost (use_2d_reprojections=False) is not built")
+    data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, est.data_path)
+    mono = scene.cam_idx is not None and init_prev_kinematic_solution
+    fte = load_result_pickle(os.path.join(data_dir, f"fte_kinematic_{scene.cam_idx}" if mono else "fte_kinematic", "fte.pickle"))
+    est.com_vel, est.com_pos = fte["com_vel"], fte["com_pos"]
+    N = params.end_frame - params.start_frame
+    if init_prev_kinematic_solution:
+        q_init = np.ascontiguousarray(fte["q"][:N], dtype=np.float64)                # acinoset_opt.py:768-777
+    else:
+        base_len = 2.0 * abs(sk.marker_off[5][0])
+        x, y, z, psi = create_trajectory_estimate(est.tables, params, scene, base_len, device=est.device)
+        q_init = np.zeros((N, sk.nq)); sl = slice(params.start_frame, params.start_frame + N)
+        q_init[:, 0], q_init[:, 1], q_init[:, 2] = x[sl], y[sl], z[sl]
+        for i in range(sk.n_links):
+            q_init[:, 3 + 3 * i + 2] = psi[sl]
+    with open(os.path.join(data_dir, "grf", "autogen-contact.json") if auto else os.path.join(params.data_dir, "metadata.json"), "r", encoding="utf-8") as fh:
+        contact_json = json.load(fh)
+    stance = stance_from_contacts(contact_json, N, params.start_frame)
+    pri = None
+    if not disable_pose_prior and scene.cam_idx is not None:                         # acinoset_opt.py:916-917
+        from . import priors as _priors
+        pri = _priors.load_priors(pose=True, motion=False)
+    opts = options if options is not None else abi.default_options(scene.fps)
+    opts.h = 1.0 / scene.fps
+    if options is None:
+        opts.tol_cost, opts.max_iter = 1e-7, 600           # the physics term is stiff: see DESIGN.md 2b (the reference stops IPOPT at Tol = 1e-3)
+    ko = kinetic_options if kinetic_options is not None else abi.default_kinetic_options(skeleton.dyn_options(est.name), scene.fps, params.kinetic_dataset)
+    if not no_slip:
+        ko.slip_max = 0.0
+    if disable_motion_prior:
+        ko.w_torque, ko.w_smooth = 0.0, 0.0                                          # acinoset_opt.py:918-920
+    if est.bound_eom_error is not None:
+        ko.slack_bound = float(max(abs(est.bound_eom_error[0]), abs(est.bound_eom_error[1])))
+    skk = skeleton.without_motion_model(sk)              # the physics-based cost has no constant-acceleration term (acinoset_opt.py:905-921)
+    h = _lib.Handle(skk, est.cams, opts, pri, device=est.device)
+    try:
+        t0 = time()
+        res = h.solve_kinetic_host(ko, q_init[None], est.meas[None], est.weight[None], stance[None])
+        est.opt_time_s = time() - t0
+        import torch
+        dev = torch.device("cuda", est.device)
+        qd = torch.tensor(res["q"], device=dev)
+        pos = torch.empty((1, N, 24, 3), dtype=torch.float64, device=dev); com = torch.empty((1, N, 3), dtype=torch.float64, device=dev)
+        h.forward_kinematics(qd, pos, com); h.synchronize()
+        est.com_pos = com[0].cpu().numpy()
+        est.com_vel = (est.com_pos[1:] - est.com_pos[:-1]) * scene.fps
+    finally:
+        h.close()
+    st, ks = res["stats"][0], res["kstats"][0]
+    est.result = res
+    est.kinetic = dict(tau=res["tau"][0], lam=res["lam"][0], grf=res["grf"][0], slack=res["slack"][0], stance=stance, ground_height=ko.ground_height)
+    est.costs = {"measurement": st.cost_meas, "pose": st.cost_pose, "energy": ks.cost_energy, "eom_error": ks.cost_eom, "torque": ks.cost_torque}
+    base_err = float(np.sqrt(np.mean((q_init[:, :6] - res["q"][0][:, :6]) ** 2)))
+    rel_err = float(np.sqrt(np.mean((q_init[:, 6:] - res["q"][0][:, 6:]) ** 2)))
+    if solver_output:
+        print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- pose: {st.cost_pose}\n-- energy: {ks.cost_energy}\n-- eom_error: {ks.cost_eom}\n"
+              f"-- torque: {ks.cost_torque}\nstatus {st.status}, {st.iterations} LM iterations, {st.outer} multiplier updates, {est.opt_time_s:.3f} s\n"
+              f"max |slack_eom| {ks.max_slack:.3e} (bound {ko.slack_bound}), max |rows 0-2| / Mg {ks.max_base_rows:.3e}, max violated inequality {ks.max_violation:.3e}\n"
+              f"RMSE base: {base_err:.4f}\nRMSE links: {rel_err:.4f}")
+    ok = st.status == abi.OK and ks.max_slack <= ko.slack_bound
+    if scene.cam_idx is not None or ok:                                              # acinoset_opt.py:948-954
+        dname = f"fte_kinetic{'_gt' if params.hand_labeled_data else ''}"
+        dname = dname if scene.cam_idx is None else f"{dname}_{scene.cam_idx}"
+        est.save(dname, fname=out_fname, out_dir_prefix=out_dir_prefix)
+    return ok
 
 
 def estimate_grf(estimator, *args, **kwargs) -> bool:
-    raise NotImplementedError("GRF re-optimisation of the kinetic trajectory (acinoset_opt.py:966-1048) belongs to the physics-based "
-                              "model, SURVEY 8 row a12, not built; the per-frame fit (row a13) is CheetahEstimator.estimate_grf")
+    raise NotImplementedError("GRF re-optimisation of the kinetic-dataset trajectory (acinoset_opt.py:966-1048: torques boxed to +-10 % of a previous "
+                              "solve, contact windows from force-plate files the reference does not ship) is not built; the physics-based solve is "
+                              "estimate_kinetics, the per-frame fit (row a13) is CheetahEstimator.estimate_grf")

@@ -288,3 +288,35 @@ def dyn_options(animal: str = "phantom") -> abi.DynOptions:
     for i, (a, b, ax) in enumerate(MOTORS):
         o.motor_first[i], o.motor_second[i], o.motor_axis[i] = LINKS.index(a), LINKS.index(b), "xyz".index(ax)
     return o
+
+
+def motor_groups():
+    """[(motor name, [columns of the torque vector])]: one entry per add_torque(first, second, about=...) of cheetah.py:70-165, its components
+    in axis order.  Names follow `<first>_<second>_torque` (the naming of the absent physical_education.motor: unpinned)."""
+    groups, order = {}, []
+    for i, (a, b, ax) in enumerate(MOTORS):
+        key = f"{a}_{b}_torque"
+        if key not in groups:
+            groups[key] = []; order.append(key)
+        groups[key].append(i)
+    return [(k, groups[k]) for k in order]
+
+
+def constraint_rows(sk: abi.Skeleton):
+    """(parent link, child link) of every joint-equality row, in the order of the constraint forces lambda: two rows per revolute joint
+    (parent.y . child.x, parent.y . child.z), one per hooke joint (cheetah.py:71-72,101,160-161)"""
+    rows = []
+    for j in range(sk.n_joints):
+        for _ in range(2 if sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y else 1):
+            rows.append((sk.joint_parent[j], sk.joint_child[j]))
+    return rows
+
+
+def without_motion_model(sk: abi.Skeleton) -> abi.Skeleton:
+    """copy of the skeleton with the constant-acceleration weights zeroed: the physics-based cost (acinoset_opt.py:905-921) has no such term"""
+    import ctypes as C
+    out = abi.Skeleton()
+    C.memmove(C.byref(out), C.byref(sk), C.sizeof(abi.Skeleton))
+    for p in range(len(out.motion_w)):
+        out.motion_w[p] = 0.0
+    return out

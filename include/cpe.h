@@ -326,7 +326,6 @@ typedef struct cpe_kinetic_options {
     double reg_force;         /* Tikhonov weight on lambda and the foot forces (1e-4): picks the minimum-norm point of a face the reference leaves open */
     double kappa_force, kappa_height, kappa_slip;     /* augmented-Lagrangian penalties (1e5, 1e6, 1e2)                          */
     double fd_step;           /* central-difference step in the reduced coordinates (1e-6)                                       */
-    double lm_damping;        /* > 0: Levenberg damping lambda * lm_damping * I on the coordinates instead of Marquardt's lambda * diag(H) */
     double lm_force_damping;  /* the node forces are eliminated from (H_ff + lambda * lm_force_damping * diag(H_ff)): the trust region
                                * also acts in FORCE space, where the walls of this problem (force bounds, friction polyhedron) are */
     int32_t inner_iterations; /* cap on the per-node Newton iterations for the forces (30)                                       */

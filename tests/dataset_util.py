@@ -8,12 +8,16 @@ import numpy as np
 from cheetah_pose_estimation_amd import skeleton, synth
 
 
-def write_dataset(root, data_path="2019_03_07/synth/run", N=30, pad=4, seed=5, n_cams=6, noise_px=1.0):
+def write_dataset(root, data_path="2019_03_07/synth/run", N=30, pad=4, seed=5, n_cams=6, noise_px=1.0, gallop=False):
     sk = skeleton.build_skeleton("phantom", 24)
     cams = synth.make_cameras(n_cams)
     rng = np.random.default_rng(seed)
     total = N + 2 * pad
-    qt = synth.truth_trajectory(sk, total, 120.0, rng)
+    stance = None
+    if gallop:                                            # planted paws (config 4): contact windows exist to be detected
+        qt, stance = synth.gallop_trajectory(sk, total, 120.0, rng)
+    else:
+        qt = synth.truth_trajectory(sk, total, 120.0, rng)
     qt[:, 0] += 6.0                                       # mid-track: every camera sees the animal
     pos, _ = synth.fk_numpy(sk, qt)
     ddir = os.path.join(root, data_path)
@@ -49,7 +53,7 @@ def write_dataset(root, data_path="2019_03_07/synth/run", N=30, pad=4, seed=5, n
         json.dump(scene, f)
     with open(os.path.join(ddir, "metadata.json"), "w") as f:
         json.dump({"start_frame": pad, "end_frame": pad + N, "cam_sync": [], "ground_plane_height": 0.0, "monocular_cam": 2}, f)
-    return dict(sk=sk, cams=cams, q_true=qt, pos_true=pos, start=pad, N=N, data_path=data_path, lik=liks)
+    return dict(sk=sk, cams=cams, q_true=qt, pos_true=pos, start=pad, N=N, data_path=data_path, lik=liks, stance=stance)
 
 
 def build_measurements_numpy(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx=None):

@@ -185,3 +185,48 @@ def test_assembled_rule_and_force_templates_against_the_reference_own_functions(
         for k, F in plates.items():
             assert np.abs(F - np.array(rec["plates"][str(k)])).max() < 1e-12, (case, k)
     assert any(len(v) > 1 for rec in Lj["contact_cases"] for v in rec["contacts"].values() if v)      # a foot with two contacts is covered
+
+
+# ---- pin on the reference's own STORED outputs ------------------------------------------------------------------
+def _stored_run():
+    """tests/golden/contacts_pin.npz (tools/pin_contacts_from_csv.py): the joint angles of the reference's monocular solution
+    `2019_03_07/phantom/run/fte_kinematic_1`, recovered from its stored 2D files cam{1..6}_fte.csv (worst pixel error 1.4e-5) with the
+    cameras of tests/golden/fk_csv_pin.npz, a ground plane fitted to the lowest paw positions (the calibration files that define the true
+    world frame are not shipped), and the contents of the stored `grf/autogen-contact.json` / `-02.json`."""
+    import os
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "contacts_pin.npz"))
+    q = Z["q"]
+    dq = np.zeros_like(q); dq[1:] = (q[1:] - q[:-1]) * 120.0; dq[0] = dq[1]     # implicit Euler; q'_0 is a free variable of the reference's NLP (not stored in 2D)
+    return Z, q, dq
+
+
+def _detect_in_fitted_frame(Z, pos, vel):
+    from cheetah_pose_estimation_amd import skeleton
+    up, off = Z["ground_normal"], float(Z["ground_offset"])
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    names = [f"{f}_foot" for f in skeleton.FEET]
+    com = pos.mean(1)                                                            # speed enters only through the stance-time line: any body point serves
+    speed = float(np.linalg.norm(np.diff(com, axis=0) * 120.0, axis=1).mean())
+    return ct.contact_detection(pos[:, feet] @ up - off, vel[:, feet] @ up, names, int(Z["start_frame"]), speed, 120.0), names
+
+
+def test_contact_heuristic_reproduces_the_reference_stored_json(oracle):
+    """FK + analytic foot velocity (oracle) + contact_detection on the reference's stored monocular solution give the windows and the
+    leading / trailing labels the reference itself wrote to grf/autogen-contact.json: start 135, end 192, HFL [168, 180] leading,
+    HFR [157, 169] trailing, HBL [155, 167] leading, HBR [144, 156] trailing -- exactly, and unchanged by +-2 cm of ground offset."""
+    from cheetah_pose_estimation_amd import skeleton
+    Z, q, dq = _stored_run()
+    sk = skeleton.build_skeleton("phantom", 24)
+    pos = oracle.markers(sk, q)
+    vel = np.array([np.einsum("ldp,p->ld", oracle.markers_jac(sk, q[n])[1], dq[n]) for n in range(q.shape[0])])
+    (contacts, by_height), names = _detect_in_fitted_frame(Z, pos, vel)
+    assert int(Z["start_frame"]) == 135 and int(Z["end_frame"]) == 192 and q.shape[0] == 57
+    for i, n in enumerate(names):
+        assert len(contacts[n]) == 1 == int(Z["n_windows"][i])
+        assert contacts[n][0][:2] == [int(Z["windows"][i][0]), int(Z["windows"][i][1])], (n, contacts[n])
+        assert contacts[n][0][3] == str(Z["labels"][i])
+    assert [contacts[n][0][:2] for n in names] == [[168, 180], [157, 169], [155, 167], [144, 156]]
+    for shift in (-0.02, 0.02):                                                  # the fitted plane is within centimetres of the true one: the result does not depend on that
+        Z2 = dict(Z); Z2["ground_offset"] = float(Z["ground_offset"]) + shift
+        (c2, _), _ = _detect_in_fitted_frame(Z2, pos, vel)
+        assert [c2[n][0][:2] for n in names] == [[168, 180], [157, 169], [155, 167], [144, 156]]

@@ -1,0 +1,145 @@
+"""Physics-based trajectory model (config 4; estimate_kinetics, acinoset_opt.py:693-963): the CPU restatement
+(oracle/cpe_oracle_kinetic.inc) checked against itself where the reference gives nothing loadable -- PARITY UNPINNED versus the reference's
+`.robot` equations of motion -- and against what the reference's text does pin: cost weights, bounds, contact windows.
+No GPU here; the HIP kernels are compared with this oracle in tests/test_gpu_parity.py."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cheetah_pose_estimation_amd import abi, skeleton, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem(N, n_cams=2, seed=4321, init_noise=0.002):
+    sk = skeleton.without_motion_model(skeleton.build_skeleton("phantom", 24))
+    cams = synth.make_cameras(n_cams)
+    opts = abi.default_options(120.0)
+    ko = abi.default_kinetic_options(skeleton.dyn_options("phantom"), 120.0)
+    d = synth.make_gallop_batch(sk, cams, B=1, N=N, seed=seed, init_noise=init_noise)
+    return sk, cams, opts, ko, d
+
+
+def test_reference_constants_of_the_physics_cost():
+    """the numbers the reference's text fixes (acinoset_opt.py:494-506, :780, :905-921; acinoset_misc.py:1140-1167; run_dataset.py:984)"""
+    ko = abi.default_kinetic_options(skeleton.dyn_options("phantom"), 120.0)
+    assert ko.w_slack == 10e3 and ko.w_torque == 1.0 and abs(ko.w_smooth - 0.1 / 120.0 ** 2) < 1e-18
+    assert ko.friction == 0.8 and ko.force_max == 5.0 and ko.grfz_min == 0.01 and ko.foot_height_tol == 0.1 and ko.slip_max == 1.0 and ko.slack_bound == 2.0
+    assert abi.default_kinetic_options(skeleton.dyn_options("arabia"), 200.0, True).foot_height_tol == 0.03
+    assert ko.dyn.n_motors == 22 and ko.dyn.n_feet == 4                      # 22 torques, 4 feet
+    sk = skeleton.build_skeleton("phantom", 24)
+    assert len(skeleton.constraint_rows(sk)) == 26                             # 26 joint constraint forces
+    assert sum(len(c) for _, c in skeleton.motor_groups()) == 22 and len(skeleton.motor_groups()) == 16
+
+
+def test_struct_sizes_of_the_dynamics_options(tmp_path):
+    """the eom / dyn / grf option structs (and the new kinetic ones) have the same size in C and in the ctypes mirror"""
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "cpe.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(cpe_eom_options), sizeof(cpe_dyn_options), '
+                   'sizeof(cpe_grf_options), sizeof(cpe_kinetic_options), sizeof(cpe_kinetic_stats));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(abi.EomOptions), C.sizeof(abi.DynOptions), C.sizeof(abi.GrfOptions), C.sizeof(abi.KineticOptions), C.sizeof(abi.KineticStats)]
+
+
+def test_gallop_generator_plants_the_paws():
+    """config-4 input (rotary gallop 3 Hz, stance 12 frames): during its stance window every paw stands still on z = 0"""
+    sk = skeleton.build_skeleton("phantom", 24)
+    q, st = synth.gallop_trajectory(sk, 200, 120.0, np.random.default_rng(4321))
+    pos, _ = synth.fk_numpy(sk, q)
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    for k in range(4):
+        on = st[:, k] == 1
+        runs = np.diff(np.flatnonzero(np.diff(np.r_[0, on, 0])))[::2]
+        assert set(runs[1:-1]) == {12}                                        # 12-frame stance, 40-frame stride
+        assert np.abs(pos[on, feet[k], 2]).max() < 1e-12
+        both = on[1:] & on[:-1]
+        assert np.abs(np.diff(pos[:, feet[k], :2], axis=0)[both]).max() < 1e-10
+        assert pos[:, feet[k], 2].min() > -1e-12
+    assert np.abs(q[:, 4::3][:, 5:]).max() < 1.5                               # no limb passes the horizontal
+    for bnd in range(sk.n_bounds):                                            # inside the joint ranges of cheetah.py:306-352
+        a, b = sk.bound_a[bnd], sk.bound_b[bnd]
+        v = q[:, a] - (q[:, b] if b >= 0 else 0)
+        assert v.max() <= sk.bound_up[bnd] and v.min() >= sk.bound_lo[bnd]
+
+
+def test_gradient_of_the_projected_objective(oracle):
+    """the node forces are minimised out exactly, so the gradient with respect to the coordinates is the partial derivative at the minimiser
+    (envelope theorem): central differences of the whole objective agree with it"""
+    sk, cams, opts, ko, d = _problem(6)
+    me, we, stn = d["meas"][0], d["weight"][0], d["stance"][0]
+    f0, g, qc, terms, _ = oracle.kinetic_objective(sk, cams, opts, None, ko, d["q_init"][0], me, we, stn)
+    assert f0 > 0 and terms[6] > 0
+    eps, worst = 1e-6, 0.0
+    rng = np.random.default_rng(0)
+    for n, k in zip(rng.integers(0, 6, 40), rng.integers(0, 28, 40)):
+        fa = oracle.kinetic_objective(sk, cams, opts, None, ko, oracle.move_coordinate(sk, qc, n, k, eps), me, we, stn, want_grad=False)[0]
+        fb = oracle.kinetic_objective(sk, cams, opts, None, ko, oracle.move_coordinate(sk, qc, n, k, -eps), me, we, stn, want_grad=False)[0]
+        fd = (fa - fb) / (2 * eps)
+        worst = max(worst, abs(fd - g[n, k]) / max(1.0, abs(fd)))
+    assert worst < 5e-4, worst
+
+
+def test_node_forces_are_a_constrained_minimiser(oracle):
+    """per node: forces of feet outside their stance window are zero, the others sit at the minimum of the node objective (any small change
+    of a free force raises it), and the eliminated matrix H_uu - H_uf H_ff^-1 H_fu is positive semi-definite"""
+    sk, cams, opts, ko, d = _problem(10, init_noise=0.0005)
+    R = oracle.kinetic_nodes(sk, cams, opts, ko, d["q_init"][0], d["stance"][0])
+    nm, nc = 22, 26
+    for n in range(2, 10):
+        na = R["meta"][n, 0]
+        assert na == nm + nc + 3 * int(d["stance"][0][n].sum())
+        F = R["f"][n][nm + nc:nm + nc + 12].reshape(4, 3)
+        assert np.all(F[d["stance"][0][n] == 0] == 0.0)
+        Hff, Hfu, Huu = R["Hff"][n][:na, :na], R["Hfu"][n][:na], R["Huu"][n]
+        assert np.linalg.eigvalsh(Hff).min() > 0
+        S = Huu - Hfu.T @ np.linalg.solve(Hff, Hfu)
+        ev = np.linalg.eigvalsh(0.5 * (S + S.T))
+        assert ev.min() > -1e-7 * ev.max()
+    assert R["stat"][:2].max() == 0.0 and R["f"][:2].max() == 0.0               # nodes 0 and 1 carry no dynamics (free q'_0, q''_0)
+
+
+def test_short_solve_respects_the_contact_rules(oracle):
+    """a 12-frame solve from a kinematic warm start: converges, the equations of motion are met to the reference's stored level
+    (|rows 0-2| / Mg <= 8e-5 x a few), forces inside their bounds and the friction polyhedron, planted paws near the ground"""
+    sk, cams, opts, ko, d = _problem(12, n_cams=6, init_noise=0.02)
+    kin = oracle.solve(skeleton.build_skeleton("phantom", 24), cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+    opts.tol_cost, opts.max_iter = 1e-7, 400
+    r = oracle.solve_kinetic(sk, cams, opts, None, ko, kin["q"], d["meas"][0], d["weight"][0], d["stance"][0])
+    st, ks = r["stats"], r["kstats"]
+    assert r["status"] == abi.OK and st.iterations < 400
+    assert ks.max_slack < 1e-2 and ks.max_slack < ko.slack_bound and ks.max_base_rows < 1e-3
+    assert ks.max_violation < 1e-4
+    g = r["grf"]                                                               # [N, 4, 5] = z, +x, +y, -x, -y
+    on = d["stance"][0] == 1
+    assert np.all(g[~on] == 0.0) and np.all(g[:2] == 0.0)
+    assert g.min() >= 0.0 and g.max() <= ko.force_max + 1e-4
+    assert np.all(g[2:][on[2:]][:, 0] >= ko.grfz_min - 1e-4)
+    assert np.all(g[..., 1:].sum(-1) <= ko.friction * g[..., 0] + 1e-4)
+    assert np.all(g[..., 1] * g[..., 3] == 0.0) and np.all(g[..., 2] * g[..., 4] == 0.0)     # x+ x- = 0: the minimum-norm split
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    hz = r["positions"][:, feet, 2]
+    assert np.abs(hz[2:][on[2:]]).max() <= ko.foot_height_tol + 1e-4 and hz[2:].min() >= -ko.foot_height_tol - 1e-4
+    # reported terms add up to the objective (acinoset_opt.py:921): 1e-3 (meas + torque + 0.1 fps^-2 energy + 10e3 eom)
+    model = ko.w_torque * ks.cost_torque + ko.w_smooth * ks.cost_energy + ko.w_slack * ks.cost_eom
+    assert abs(st.cost_model - model) < 1e-9 * model and abs(st.cost - 1e-3 * (st.cost_meas + model)) < 1e-9 * st.cost
+    assert np.abs(r["slack"][:2]).max() == 0.0 and np.abs(r["tau"][:2]).max() == 0.0
+
+
+def test_stored_contact_windows_become_stance_flags():
+    """the reference's own stored `autogen-contact.json` of 2019_03_07/phantom/run (tests/golden/contacts_pin.npz holds its numbers):
+    windows of 13 frames (12-frame stance at 120 fps, both ends included as in acinoset_opt.py:787-798) turn into the stance table"""
+    from cheetah_pose_estimation_amd import estimator as E
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "contacts_pin.npz"))
+    names = [f"{f}_foot" for f in skeleton.FEET]
+    cj = {"start_frame": int(Z["start_frame"]), "end_frame": int(Z["end_frame"]),
+          "contacts": {n: [[int(w[0]), int(w[1]), i, str(l)]] for i, (n, w, l) in enumerate(zip(names, Z["windows"], Z["labels"]))}}
+    assert cj["start_frame"] == 135 and cj["end_frame"] == 192
+    st = E.stance_from_contacts(cj, 57, 135)
+    assert st.shape == (57, 4) and list(st.sum(0)) == [13, 13, 13, 13]
+    assert [int(np.flatnonzero(st[:, k])[0]) + 135 for k in range(4)] == [168, 157, 155, 144]          # HFL, HFR, HBL, HBR
