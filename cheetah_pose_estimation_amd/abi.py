@@ -110,7 +110,7 @@ class KineticOptions(C.Structure):
                 ("force_max", C.c_double), ("grfz_min", C.c_double), ("foot_height_tol", C.c_double), ("foot_height_min", C.c_double),
                 ("ground_height", C.c_double), ("slip_max", C.c_double), ("slack_bound", C.c_double), ("reg_force", C.c_double),
                 ("kappa_force", C.c_double), ("kappa_height", C.c_double), ("kappa_slip", C.c_double), ("fd_step", C.c_double),
-                ("lm_force_damping", C.c_double), ("inner_iterations", C.c_int32), ("_pad", C.c_int32)]
+                ("lm_force_damping", C.c_double), ("lm_wall_damping", C.c_double), ("inner_iterations", C.c_int32), ("_pad", C.c_int32)]
 
 
 class KineticStats(C.Structure):
@@ -129,7 +129,7 @@ def default_kinetic_options(dyn: DynOptions, fps: float = 120.0, kinetic_dataset
     o.foot_height_tol = 0.03 if kinetic_dataset else 0.1
     o.foot_height_min, o.ground_height, o.slip_max, o.slack_bound = 0.0, 0.0, 1.0, 2.0
     o.reg_force, o.kappa_force, o.kappa_height, o.kappa_slip, o.fd_step = 1e-4, 1e5, 1e6, 1e2, 1e-6
-    o.lm_force_damping = 30.0
+    o.lm_force_damping, o.lm_wall_damping = 10.0, 10.0
     o.inner_iterations = 30
     return o
 

@@ -852,7 +852,7 @@ void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kin
     // o->dyn (inertias, feet, motors) is the caller's
     o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
     o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->slack_bound = 2.0;
-    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 30.0;
+    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0;
     o->inner_iterations = 30; o->_pad = 0;
 }
 
@@ -971,7 +971,7 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
                            h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, nullptr, act, n_act, 2);
         prof_end(h);
         prof_begin(h, 6);
-        hipLaunchKernelGGL(k_dyn_schur, dim3(gf), dim3(KIN_THREADS), lds_kin_schur(), h->stream, h->dk, h->st, N, Fw, h->pieces, h->pmeta, h->Tbuf, act, n_act);
+        hipLaunchKernelGGL(k_dyn_schur, dim3(gf), dim3(KIN_THREADS), lds_kin_schur(), h->stream, h->dk, h->st, N, Fw, h->pieces, h->pmeta, h->fbuf, h->kmu, stance, h->Tbuf, act, n_act);
         hipLaunchKernelGGL(k_dyn_gather, dim3(gf), dim3(KIN_THREADS), 0, h->stream, h->st, N, Fw, h->gbuf, h->Bbuf, h->Tbuf, h->gTb, h->gk, h->Bk, h->Hk, act, n_act);
         prof_end(h);
         prof_begin(h, 2);

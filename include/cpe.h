@@ -326,8 +326,10 @@ typedef struct cpe_kinetic_options {
     double reg_force;         /* Tikhonov weight on lambda and the foot forces (1e-4): picks the minimum-norm point of a face the reference leaves open */
     double kappa_force, kappa_height, kappa_slip;     /* augmented-Lagrangian penalties (1e5, 1e6, 1e2)                          */
     double fd_step;           /* central-difference step in the reduced coordinates (1e-6)                                       */
-    double lm_force_damping;  /* the node forces are eliminated from (H_ff + lambda * lm_force_damping * diag(H_ff)): the trust region
+    double lm_force_damping;  /* the node forces are eliminated from (H_ff + lambda * lm_force_damping * diag(H_ff) + walls): the trust region
                                * also acts in FORCE space, where the walls of this problem (force bounds, friction polyhedron) are */
+    double lm_wall_damping;   /* walls: + lambda * lm_wall_damping * 2 w_slack * sum over the INACTIVE force inequalities c c^T / gap^2
+                               * (the Hessian of a log barrier, affine-scaling trust region): forces near a bound are held back in the model */
     int32_t inner_iterations; /* cap on the per-node Newton iterations for the forces (30)                                       */
     int32_t _pad;
 } cpe_kinetic_options;

@@ -869,7 +869,7 @@ static cpe_status solve_impl(const cpe_skeleton* s, const cpe_camera* cams, int 
         /* (H + lam diag(H)) dl = -g */
         memcpy(abf, ab, sizeof(double) * (size_t)n_tot * (kd + 1));
         if (K) {            /* physics terms: Schur complement of the node forces, damped in force space with the same lambda */
-            kin_add_schur(&x, N, kd, lam * K->ko->lm_force_damping, abf);
+            kin_add_schur(&x, N, kd, lam, abf);
             memcpy(abm, abf, sizeof(double) * (size_t)n_tot * (kd + 1));        /* the model matrix of this iteration (for pred) */
         }
         for (int i = 0; i < n_tot; i++) { double d = abf[(size_t)i * (kd + 1)]; abf[(size_t)i * (kd + 1)] = d + lam * (d > 1e-12 ? d : 1e-12); }
@@ -967,7 +967,7 @@ void cpo_default_kinetic_options(cpe_kinetic_options* o, double fps, int kinetic
     /* o->dyn (inertias, feet, motors) is the caller's */
     o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
     o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->slack_bound = 2.0;
-    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 30.0; o->inner_iterations = 30; o->_pad = 0;
+    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0; o->inner_iterations = 30; o->_pad = 0;
 }
 
 /* objective of the physics-based model at a point (multipliers zero), its reduced gradient and, optionally, the band matrix:

@@ -51,8 +51,17 @@ def write_dataset(root, data_path="2019_03_07/synth/run", N=30, pad=4, seed=5, n
                                  "r": np.array(cam.R[:]).reshape(3, 3).tolist(), "t": [[cam.t[i]] for i in range(3)]})
     with open(os.path.join(root, data_path.split("/")[0], "extrinsic_calib", f"{n_cams}_cam_scene_sba.json"), "w") as f:
         json.dump(scene, f)
+    md = {"start_frame": pad, "end_frame": pad + N, "cam_sync": [], "ground_plane_height": 0.0, "monocular_cam": 2}
+    if stance is not None:
+        # hand-entered contact windows, as the reference's metadata.json carries them for `auto=False` (acinoset_opt.py:783-790):
+        # {foot: [[first frame, last frame], ...]} in absolute frame numbers, both ends included
+        md["contacts"] = {}
+        for k, foot in enumerate(skeleton.FEET):
+            on = np.flatnonzero(stance[:, k])
+            runs = np.split(on, np.flatnonzero(np.diff(on) > 1) + 1) if len(on) else []
+            md["contacts"][f"{foot}_foot"] = [[int(r[0]), int(r[-1]), k, "TBD"] for r in runs] or None
     with open(os.path.join(ddir, "metadata.json"), "w") as f:
-        json.dump({"start_frame": pad, "end_frame": pad + N, "cam_sync": [], "ground_plane_height": 0.0, "monocular_cam": 2}, f)
+        json.dump(md, f)
     return dict(sk=sk, cams=cams, q_true=qt, pos_true=pos, start=pad, N=N, data_path=data_path, lik=liks, stance=stance)
 
 

@@ -94,13 +94,15 @@ def test_estimate_kinetics_end_to_end_from_files(tmp_path, gpu_handle_factory):
     info = write_dataset(str(tmp_path), N=48, noise_px=0.5, gallop=True)
     est = E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, solver_path="/unused/ipopt", kinematic_model=True)
     assert E.estimate_kinematics(est, solver_output=False) is True
-    contacts, _ = E.determine_contacts(est, verbose=False)
-    assert sum(len(v or []) for v in contacts.values()) >= 2
+    contacts, _ = E.determine_contacts(est, verbose=False)                      # writes grf/autogen-contact*.json + the template forces
+    assert sum(len(v or []) for v in contacts.values()) >= 2 and os.path.exists(os.path.join(est.params.data_dir, "grf", "autogen-contact.json"))
+    # (this synthetic gait lifts its paws by 5 cm only, below the heuristic's 5 cm height threshold, so the detected windows are
+    # not the planted ones; the physics-based solve below takes the windows from metadata.json, the reference's `auto=False` path)
     est2 = E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, solver_path="/unused/ipopt", enable_eom_slack=True,
                              bound_eom_error=(-2.0, 2.0), include_camera_constraints=True, kinematic_model=False)        # the reference's default is kinematic_model=False
     with pytest.raises(AssertionError):
         E.estimate_kinetics(est, joint_estimation=True)                          # a kinematic model has no equations of motion
-    ok = E.estimate_kinetics(est2, init_torques=False, init_prev_kinematic_solution=True, solver_output=False, auto=True, joint_estimation=True)
+    ok = E.estimate_kinetics(est2, init_torques=False, init_prev_kinematic_solution=True, solver_output=False, auto=False, joint_estimation=True)
     assert ok is True
     out_dir = os.path.join(str(tmp_path), info["data_path"], "fte_kinetic")
     d = E.load_result_pickle(os.path.join(out_dir, "fte.pickle"))
@@ -115,6 +117,10 @@ def test_estimate_kinetics_end_to_end_from_files(tmp_path, gpu_handle_factory):
     assert os.path.exists(os.path.join(out_dir, "cam6_fte.csv"))
     truth = info["pos_true"][4:52]
     assert np.sqrt(((d["positions"] - truth) ** 2).sum(-1).mean()) < 0.03
+    st = info["stance"][4:52]
+    assert np.all(est2.kinetic["stance"] == st)
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    assert np.abs(d["positions"][2:, feet, 2][st[2:] == 1]).max() < 0.1 + 1e-3       # planted paws stay within the foot-height tolerance
 
 
 def test_gpu_kinematics_reproduce_the_reference_stored_contact_json(gpu_handle_factory):
