@@ -3,7 +3,7 @@ import ctypes as C
 
 MAX_LINKS = 20
 MAX_MARKERS = 32
-MAX_CAMS = 8
+MAX_CAMS = 18
 MAX_JOINTS = 16
 MAX_BOUNDS = 32
 MAX_NQ = 3 + 3 * MAX_LINKS

@@ -144,6 +144,48 @@ def build_measurements(tables, start_frame: int, end_frame: int, sync_offset, n_
         h.close()
 
 
+def load_pairwise_table(path: str):
+    """pairwise predictions of ONE camera (`dlc_pw/cam?DLC_....pickle`, acinoset_misc.py:202-205): per table row the DLC pose row [75] and the
+    pairwise offsets `pws` [1, 25, 25, 2] (offset from body part a to body part b).  Accepted here: an `.npz` with arrays `pose [rows, 75]`,
+    `pws [rows, 25, 25, 2]`, or the reference's pickle read with the arrays-only unpickler (a list of {"pose", "pws"} records)."""
+    if path.endswith(".npz"):
+        z = np.load(path, allow_pickle=False)
+        return np.asarray(z["pose"], dtype=np.float64), np.asarray(z["pws"], dtype=np.float64)
+    recs = load_result_pickle(path)
+    pose = np.array([np.asarray(r["pose"], dtype=np.float64).ravel() for r in recs])
+    pws = np.array([np.asarray(r["pws"], dtype=np.float64).reshape(25, 25, 2) for r in recs])
+    return pose, pws
+
+
+def build_pairwise_measurements(pw_tables, start_frame: int, end_frame: int, sync_offset, n_cams: int, dlc_thresh: float, kinetic_dataset: bool,
+                                cam_idx: Optional[int] = None):
+    """meas[N, 2, C, 24, 2] and weight[N, 2, C, 24] of the two pairwise pseudo-measurements w = 2, 3 as `init_measurements` / `init_meas_weights`
+    fill them (acinoset_misc.py:211-256): marker l is predicted from body part b = pair_dict[marker][w - 2] as pose[b] + pws[b, dlc index of the
+    marker]; weight 1 / R_pw[w - 1][l] if the likelihood of b exceeds the threshold.  Host gather over a few thousand numbers."""
+    off = [0] * n_cams
+    if sync_offset is not None:
+        for o in sync_offset:
+            off[o["cam"]] = o["frame"]
+    N = end_frame - start_frame
+    cams = list(range(n_cams)) if cam_idx is None else [cam_idx]
+    meas = np.zeros((N, 2, len(cams), 24, 2)); weight = np.zeros((N, 2, len(cams), 24))
+    own = np.array([skeleton.DLC_INDEX[m] for m in skeleton.MARKERS])
+    for w in (0, 1):
+        sig = skeleton.pairwise_sigma(w + 1, kinetic_dataset)
+        src = np.array([skeleton.PAIRWISE[m][w] for m in skeleton.MARKERS])
+        for ci, c in enumerate(cams):
+            pose, pws = pw_tables[c]
+            rows = np.arange(N) + start_frame - off[c]
+            ok = (rows >= 0) & (rows < pose.shape[0])
+            r = np.clip(rows, 0, pose.shape[0] - 1)
+            xy = np.stack([pose[r][:, 0::3][:, src] + pws[r][:, src, own, 0], pose[r][:, 1::3][:, src] + pws[r][:, src, own, 1]], axis=-1)
+            lik = pose[r][:, 2::3][:, src]
+            good = ok[:, None] & np.isfinite(xy).all(-1)
+            meas[:, w, ci] = np.where(good[..., None], xy, 0.0)
+            weight[:, w, ci] = np.where(good & (lik > dlc_thresh), 1.0 / sig[None, :], 0.0)
+    return meas, weight
+
+
 def scene_cameras(scene: Scene, kinetic_dataset: bool):
     """abi.Camera array from the scene; multipliers [1,1,.6,.6] for the kinetic dataset (acinoset_misc.py:462-464)."""
     idx = list(range(scene.n_cams)) if scene.cam_idx is None else [scene.cam_idx]
@@ -288,6 +330,13 @@ class CheetahEstimator:
         grfxy_est = {f: [[float(v) for v in row] for row in gxy[0, :, i]] for i, f in enumerate(feet)}
         return grfz_est, grfxy_est
 
+    def folded_meas_err(self) -> np.ndarray:
+        """slack_meas as the reference stores it, [N, C, 24, 2, W] (acinoset_opt.py:325): the solver's camera axis is [w * C + c] with PPM"""
+        me = self.result["meas_err"][0]
+        W = 3 if self.params.enable_ppms else 1
+        C1 = me.shape[1] // W
+        return np.ascontiguousarray(np.stack([me[:, w * C1:(w + 1) * C1] for w in range(W)], axis=-1))
+
     def robot_data(self) -> dict:
         """`cheetah.pickle` of a physics-based run: the layout `System3D.save_data_to_file` gives the reference's files (SURVEY 8b:
         name, description, nfe, ncp, hm, hm0, links: [{name, is_base, mass, length, radius, q, dq, ddq, Fr, nodes}]): per link the
@@ -333,7 +382,7 @@ class CheetahEstimator:
                 tau[name] = np.ascontiguousarray(self.kinetic["tau"][:, cols])
         output = dict(positions=res["positions"][0], x=self.relative_angles(q), dx=self.relative_angles(dq),
                       ddx=self.relative_angles(ddq), q=q, dq=dq, ddq=ddq, com_pos=self.com_pos, com_vel=self.com_vel,
-                      tau=tau, meas_err=res["meas_err"][0][..., None], obj_cost=self.get_objective_cost(),
+                      tau=tau, meas_err=self.folded_meas_err(), obj_cost=self.get_objective_cost(),
                       processing_time_s=self.opt_time_s, start_frame=params.start_frame)
         with open(os.path.join(out_dir, f"{fname}.pickle"), "wb") as f:
             pickle.dump(output, f)
@@ -377,8 +426,8 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
                     device: int = 0) -> CheetahEstimator:
     """Same signature and meaning as acinoset_opt.init_trajectory (acinoset_opt.py:413-536).  `solver_path`
     (the IPOPT binary of the reference) is accepted and ignored."""
-    if shutter_delay_estimation or enable_ppm or hand_labeled_data:
-        raise NotImplementedError("shutter delay / pairwise pseudo-measurements / hand labels are SURVEY 8f-4 (next)")
+    if shutter_delay_estimation or hand_labeled_data:
+        raise NotImplementedError("shutter-delay estimation (SURVEY 8f-4, second half) and hand-labelled data are not built")
     if cheetah_name not in ("jules", "phantom", "shiraz", "arabia"):
         cheetah_name = "acinoset"                                   # acinoset_opt.py:455-456
     model_name = f"{cheetah_name}-02" if kinetic_dataset else cheetah_name
@@ -408,8 +457,25 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
     tables = [load_dlc_table(p) for p in paths]
     sk = skeleton.build_skeleton(model_name, 24, kinetic_dataset)
     meas, weight = build_measurements(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx, device=device)
+    cams = scene_cameras(scene, kinetic_dataset)
+    if enable_ppm:
+        # m.W = RangeSet(3) (acinoset_misc.py:179): the SAME projected marker is compared with three detections -- its own and two pairwise
+        # predictions --, each with its own weight.  For the kernels that is every camera three times with identical parameters: cameras
+        # [w * C + c], measurement slices [N, w * C + c, 24, ...]; CheetahEstimator.save folds the residuals back to [N, C, 24, 2, 3].
+        pw_paths = sorted(glob(os.path.join(dlc_dir + "_pw", "*.npz"))) or sorted(glob(os.path.join(dlc_dir + "_pw", "*.pickle")))
+        assert n_cams == len(pw_paths), f"# of pairwise files != # of cams in {scene_fpath}"
+        pm, pw = build_pairwise_measurements([load_pairwise_table(p) for p in pw_paths], start_frame, end_frame, sync_offset, n_cams, dlc_thresh,
+                                             kinetic_dataset, cam_idx)
+        C1 = len(cams)
+        meas = np.ascontiguousarray(np.concatenate([meas] + [pm[:, w] for w in range(2)], axis=1))
+        weight = np.ascontiguousarray(np.concatenate([weight] + [pw[:, w] for w in range(2)], axis=1))
+        cams3 = (abi.Camera * (3 * C1))()
+        for w in range(3):
+            for c in range(C1):
+                cams3[w * C1 + c] = cams[c]
+        cams = cams3
     total_mass = sum(sk.mass[i] for i in range(sk.n_links))
-    return CheetahEstimator(cheetah_name, data_path, params, scene, sk, scene_cameras(scene, kinetic_dataset), meas, weight,
+    return CheetahEstimator(cheetah_name, data_path, params, scene, sk, cams, meas, weight,
                             total_mass * 9.81, kinematic_model, tables, device, enable_eom_slack=enable_eom_slack, bound_eom_error=bound_eom_error)
 
 

@@ -320,3 +320,22 @@ def without_motion_model(sk: abi.Skeleton) -> abi.Skeleton:
     for p in range(len(out.motion_w)):
         out.motion_w[p] = 0.0
     return out
+
+
+# ---- pairwise pseudo-measurements (PPM, acinoset_misc.py:179, :211-256; enabled for the "flick" clips, run_dataset.py:1323) -----------
+# R_pw rows 1 and 2 of get_uncertainty_models (acinoset_misc.py:1791-1847; doubled at :1850 like row 0) and get_pairwise_graph (:1972-1998):
+# the two DLC body parts each marker is also predicted FROM (DLC part index, not marker index).  tests/test_oracle_golden.py compares these
+# tables with the values the reference's own functions return (tests/golden/misc_golden.npz, misc_names.json).
+R_PW1 = np.array([2.71, 3.06, 2.99, 4.07, 5.53, 4.67, 6.05, 5.6, 5.01, 5.11, 5.24, 4.85, 5.18, 5.28, 5.5, 4.9, 4.7, 4.7, 5.21, 5.11, 5.1, 5.27, 5.75, 5.44])
+R_PW2 = np.array([2.8, 3.24, 3.42, 3.8, 4.4, 5.43, 5.22, 7.29, 8.19, 6.5, 5.9, 6.18, 8.83, 6.52, 6.22, 6.34, 6.8, 6.12, 5.37, 5.98, 7.83, 6.44, 6.1, 6.38])
+PAIRWISE = {"r_eye": (23, 1), "l_eye": (23, 0), "nose": (0, 1), "neck_base": (6, 23), "spine": (22, 24), "tail_base": (6, 11), "tail1": (6, 22),
+            "tail2": (11, 22), "l_shoulder": (14, 24), "l_front_knee": (13, 15), "l_front_ankle": (13, 14), "l_front_paw": (14, 15),
+            "r_shoulder": (3, 24), "r_front_knee": (2, 4), "r_front_ankle": (2, 3), "r_front_paw": (3, 4), "l_hip": (18, 22), "l_back_knee": (17, 19),
+            "l_back_ankle": (17, 18), "l_back_paw": (18, 19), "r_hip": (8, 22), "r_back_knee": (7, 9), "r_back_ankle": (7, 8), "r_back_paw": (8, 9)}
+
+
+def pairwise_sigma(w: int, kinetic_dataset: bool = False) -> np.ndarray:
+    """R_pw[w] (w = 0: the detection itself, 1, 2: the two pairwise predictions), doubled (acinoset_misc.py:1850); 7 for the kinetic dataset (:187-188)"""
+    if kinetic_dataset:
+        return np.full(24, 7.0)
+    return 2.0 * (R_MEAS, R_PW1, R_PW2)[w]

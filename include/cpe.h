@@ -28,7 +28,8 @@ extern "C" {
 
 #define CPE_MAX_LINKS 20
 #define CPE_MAX_MARKERS 32
-#define CPE_MAX_CAMS 8
+#define CPE_MAX_CAMS 18      /* 6 cameras x 3: with pairwise pseudo-measurements (m.W = RangeSet(3), acinoset_misc.py:179) every camera
+                              * appears three times with the same parameters and its own meas / weight slice */
 #define CPE_MAX_JOINTS 16
 #define CPE_MAX_BOUNDS 32
 #define CPE_MAX_NQ (3 + 3 * CPE_MAX_LINKS)

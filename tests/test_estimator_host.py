@@ -83,3 +83,30 @@ def test_result_pickle_reader_executes_nothing(tmp_path):
         pickle.dump(dict(q=Evil()), f)
     with pytest.raises(pickle.UnpicklingError):
         E.load_result_pickle(str(p))
+
+
+def test_pairwise_pseudo_measurements_follow_the_reference_rule(tmp_path):
+    """SURVEY 8f-4, PPM (m.W = RangeSet(3), acinoset_misc.py:179, :211-256): the tables shipped in the package equal the reference's own
+    (golden values produced by calling get_uncertainty_models / get_pairwise_graph), and the vectorised tensorisation equals the loop form"""
+    import json
+    import os
+    from dataset_util import build_pairwise_numpy
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "misc_golden.npz"))
+    names = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "misc_names.json")))
+    for w in range(3):
+        assert np.array_equal(skeleton.pairwise_sigma(w), G["R_pw"][w])
+    assert np.all(skeleton.pairwise_sigma(2, True) == 7.0)
+    assert {k: list(v) for k, v in skeleton.PAIRWISE.items()} == names["pairwise"]
+    info = write_dataset(str(tmp_path), N=12, ppm=True)
+    ddir = os.path.join(str(tmp_path), info["data_path"])
+    tabs = [E.load_pairwise_table(os.path.join(ddir, "dlc_pw", f)) for f in sorted(os.listdir(os.path.join(ddir, "dlc_pw")))]
+    assert len(tabs) == 6 and tabs[0][0].shape == (20, 75) and tabs[0][1].shape == (20, 25, 25, 2)
+    sync = [{"cam": 2, "frame": 1}]
+    m, w = E.build_pairwise_measurements(tabs, 4, 16, sync, 6, 0.5, False)
+    mo, wo = build_pairwise_numpy(tabs, 4, 16, sync, 6, 0.5, False)
+    assert m.shape == (12, 2, 6, 24, 2) and np.array_equal(m * (w[..., None] > 0), mo * (wo[..., None] > 0)) and np.array_equal(w, wo)
+    assert (w > 0).mean() > 0.5
+    # a pairwise prediction really predicts the marker: within the synthetic noise of its true projection
+    l = skeleton.MARKERS.index("r_front_paw")
+    uv0, _ = synth.project_numpy(info["cams"][0], info["pos_true"][4:16, l])
+    assert np.abs(m[:, 0, 0, l] - uv0).max() < 12.0

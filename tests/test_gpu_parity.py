@@ -877,3 +877,35 @@ def test_full_size_properties(sk25, cams6, gpu_handle_factory):
     assert float((q[:P] - q[Bs - P:]).abs().max()) < 1e-9                       # and land on the same trajectory (LDS atomics reorder sums)
     err = float(((pos[:P] - torch.tensor(synth.fk_numpy(sk25, d["q_true"])[0], device=dev)) ** 2).sum(-1).mean().sqrt())
     assert err < 0.02                                                           # 2 px noise, 10 % outliers: centimetre level
+
+
+def test_pairwise_pseudo_measurements_end_to_end(tmp_path, oracle):
+    """SURVEY 8f-4, first half: `enable_ppm=True` (run_dataset.py:1323).  Three detections per (camera, marker) -- its own and two pairwise
+    predictions -- enter the kernels as 18 camera slices; the solve matches the oracle on the same 18-slice problem, the residuals come back
+    folded to the reference's [N, C, 24, 2, 3] and the pseudo-measurements pull their weight (they change the solution)."""
+    import os
+    from cheetah_pose_estimation_amd import estimator as E
+    from dataset_util import write_dataset
+    info = write_dataset(str(tmp_path), N=24, ppm=True)
+    est = E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, solver_path="/unused", kinematic_model=True, enable_ppm=True)
+    assert len(est.cams) == 18 and est.meas.shape == (24, 18, 24, 2) and est.weight.shape == (24, 18, 24)
+    assert E.estimate_kinematics(est, solver_output=False) is True
+    d = E.load_result_pickle(os.path.join(str(tmp_path), info["data_path"], "fte_kinematic", "fte.pickle"))
+    assert d["meas_err"].shape == (24, 6, 24, 2, 3)
+    assert np.array_equal(d["meas_err"][..., 1], est.result["meas_err"][0][:, 6:12])
+    # same 18-slice problem through the oracle, from the same initial guess the estimator built
+    opts = abi.default_options(120.0)
+    base_len = 2.0 * abs(est.skeleton.marker_off[5][0])
+    x, y, z, psi = E.create_trajectory_estimate(est.tables, est.params, est.scene, base_len)
+    q0 = np.zeros((24, 54)); q0[:, 0], q0[:, 1], q0[:, 2] = x[4:28], y[4:28], z[4:28]
+    for i in range(17):
+        q0[:, 3 + 3 * i + 2] = psi[4:28]
+    ref = oracle.solve(est.skeleton, est.cams, opts, None, q0, est.meas, est.weight)
+    assert ref["stats"].status == abi.OK
+    assert np.sqrt(((d["positions"] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-5
+    # without the pseudo-measurements the answer differs
+    est1 = E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, solver_path="/unused", kinematic_model=True)
+    assert E.estimate_kinematics(est1, solver_output=False, out_dir_prefix=os.path.join(str(tmp_path), "noppm")) is True
+    assert np.abs(est1.result["positions"][0] - d["positions"]).max() > 1e-4
+    truth = info["pos_true"][4:28]
+    assert np.sqrt(((d["positions"] - truth) ** 2).sum(-1).mean()) < 0.03
