@@ -149,19 +149,26 @@ def cpu_baseline(sk, cams, opts, d, budget_s=8.0):
                                   solves_per_s=nb / tm, solve_sample=f"{nb} sequences on {us} threads, {tm:.1f} s, {float(its.mean()):.1f} iterations on average"))
 
 
-def pmc_traffic(B, N, C, L):
-    """HBM bytes per k_resjac launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_resjac.json:
-    separate FETCH_SIZE / WRITE_SIZE runs, read side doubled per MI355X_MICROARCH.md), scaled per frame.
-    None if no profile for this marker/camera count is committed."""
+def pmc_traffic(B, N, C, L, kernel="k_resjac"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc*.json, tools/summarise_pmc.py: separate
+    FETCH_SIZE / WRITE_SIZE runs, read side doubled per MI355X_MICROARCH.md), scaled per frame.  The newest round's file wins.
+    None if no profile for this marker / camera count (or kernel) is committed."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_resjac.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json"))):
         try:
             with open(f) as fh:
                 j = json.load(fh)
-            c = j["config"]
-            if c["C"] == C and c["L"] == L:
-                best = j["hbm_bytes_per_launch"]["total_corrected"] / (c["B"] * c["N"]) * (B * N)
+            if "kernels" in j:                                   # round 2 format: several kernels, frames per launch stated
+                if j.get("config", {}).get("C") != C or j.get("config", {}).get("L") != L:
+                    continue
+                for name, k in j["kernels"].items():
+                    if k and kernel in name:
+                        best = k["total_corrected"] / j["frames_per_launch"] * (B * N)
+            else:                                                # round 1 format: k_resjac only
+                c = j["config"]
+                if kernel == "k_resjac" and c["C"] == C and c["L"] == L:
+                    best = j["hbm_bytes_per_launch"]["total_corrected"] / (c["B"] * c["N"]) * (B * N)
         except Exception:
             pass
     return best
@@ -350,7 +357,8 @@ def main():
         wframe_its = float((np.array([s.iterations for s in wstats]) + 1).sum()) * N
         roof = {"bound": "hbm", "kernel": "k_lm_step<3>", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
                 "achieved": (lm_b * wframe_its / (lm_ms * 1e-3) / 1e9) if lm_ms else None,
-                "frac": (lm_b * wframe_its / (lm_ms * 1e-3) / HBM_PEAK) if lm_ms else None, "traffic": None,
+                "frac": (lm_b * wframe_its / (lm_ms * 1e-3) / HBM_PEAK) if lm_ms else None,
+                "traffic": pmc_traffic(min(Bs, 512), N, C, L, "k_lm_step"),          # per full launch window (512 sequences)
                 "bytes_per_frame_iteration": lm_b, "kernel_ms_total": lm_ms, "launches": lm_n,
                 "fp64": {"achieved_tflops": (lm_flops_per_frame_iteration() * wframe_its / (lm_ms * 1e-3) / 1e12) if lm_ms else None,
                          "peak_tflops": FP64_PEAK / 1e12,
