@@ -20,7 +20,25 @@ import os
 import sys
 
 
+def collect_db(d, counter, kernel):
+    """rocprofv3's default output on ROCm 7.2 is a rocpd SQLite database: view `counters_collection` has one row per dispatch, counter (and
+    dimension instance)"""
+    import sqlite3
+    per, meta = {}, {}
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        db = sqlite3.connect(f)
+        for did, val, grid, vgpr, lds, wg in db.execute(
+                "select dispatch_id, value, grid_size, vgpr_count, lds_block_size, workgroup_size from counters_collection where counter_name = ? and kernel_name like ?",
+                (counter, "%" + kernel + "%")):
+            per[did] = per.get(did, 0.0) + float(val)
+            meta = dict(grid=grid, vgpr=vgpr, lds=lds, wg=wg)
+    return [per[k] for k in sorted(per)], meta
+
+
 def collect(d, counter, kernel):
+    v, m = collect_db(d, counter, kernel)
+    if v:
+        return v, m
     per, meta = {}, {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
