@@ -77,6 +77,8 @@ def load():
     lib.cpe_tensorise_dlc.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_double, vp, vp]
     lib.cpe_eval_normal.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cpe_solve.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
+    lib.cpe_solve_shutter.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_double, C.c_int32, C.c_double, vp, vp, vp, vp, vp, vp,
+                                      C.POINTER(abi.Stats), C.POINTER(C.c_int32)]
     lib.cpe_solve_host.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Stats)]
     lib.cpe_eom_rows.argtypes = [vp, C.POINTER(abi.EomOptions), C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.cpe_eom_residual.argtypes = [vp, C.POINTER(abi.DynOptions), C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
@@ -287,6 +289,33 @@ class Handle:
         self._leave()
         _check(st, "cpe_solve", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
         return st, list(stats)[:B]
+
+    def solve_shutter(self, q_init, meas, weight, tau_bound, q, dq, ddq, positions, meas_err, tau, max_rounds=8, tol_tau=1e-6):
+        """trajectory + per-camera shutter delays (acinoset_misc.py:283-285); device tensors, tau [B, C]"""
+        B, N = q_init.shape[0], q_init.shape[1]
+        stats = (abi.Stats * max(B, 1))()
+        rounds = C.c_int32(0)
+        self._enter()
+        st = self.lib.cpe_solve_shutter(self._h, B, N, _ptr(q_init), _ptr(meas), _ptr(weight), float(tau_bound), int(max_rounds), float(tol_tau),
+                                        _ptr(q), _ptr(dq), _ptr(ddq), _ptr(positions), _ptr(meas_err), _ptr(tau), stats, C.byref(rounds))
+        self._leave()
+        _check(st, "cpe_solve_shutter", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
+        return st, list(stats)[:B], rounds.value
+
+    def solve_shutter_host(self, q_init, meas, weight, tau_bound, max_rounds=8, tol_tau=1e-6):
+        """numpy in, numpy out (staged through HBM with torch)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        T = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+        E = lambda *sh: torch.empty(sh, dtype=torch.float64, device=dev)
+        qi, me, we = T(q_init), T(meas), T(weight)
+        B, N, nq = qi.shape
+        q, dq, ddq = E(B, N, nq), E(B, N, nq), E(B, N, nq)
+        pos, err, tau = E(B, N, self.L, 3), E(B, N, self.n_cams, self.L, 2), E(B, self.n_cams)
+        st, stats, rounds = self.solve_shutter(qi, me, we, tau_bound, q, dq, ddq, pos, err, tau, max_rounds, tol_tau)
+        self.synchronize()
+        return dict(status=st, q=q.cpu().numpy(), dq=dq.cpu().numpy(), ddq=ddq.cpu().numpy(), positions=pos.cpu().numpy(),
+                    meas_err=err.cpu().numpy(), tau=tau.cpu().numpy(), stats=stats, rounds=rounds)
 
     def eom_rows(self, eopt, q, dq, ddq, rows):
         """all rows of d/dt dL/dq' - dL/dq (device tensors [B, N, nq])"""

@@ -58,6 +58,12 @@ struct cpe_handle {
     int pb = 3;                  // half-bandwidth of the normal equations in frames (4 with a window-4 motion prior)
 };
 
+struct DevBuf {
+    double* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(double) * (n ? n : 1)); }
+};
+
 static double host_rho0(double a, double b, double c) {
     // rho(0) of acinoset_misc.py:2001-2015
     auto sg = [](double t) { return 1.0 / (1.0 + std::exp(t)); };   // s(t, 0) = 1/(1+e^{t})
@@ -336,12 +342,13 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
 }
 
 static size_t lds_fk(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C); }
-static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0) {
+static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0, bool shutter = false) {
     // H | g overlay the solver-slot vectors dp and the S rows (dead once Dp is built): the larger of the two
     size_t ov = 3 * m.ss_n + CPE_MAX_SCOL * m.ndep, hg = m.nu * m.nu + m.nu;
     size_t n = m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.n_trunk + 3 * m.L + 3 * m.sv_n + GAM_STRIDE * m.nrev + (ov > hg ? ov : hg) +
                9 * m.L + 3 * m.mc_total;
     if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX + gmm_dim * gmm_dim + 2 * gmm_dim * m.nu;
+    if (shutter) n += 15 * m.C + 6 * m.L + 6;          // shift | coefficients | rc | Mc per camera, M1 per marker, M2
     return sizeof(double) * n;
 }
 
@@ -745,26 +752,27 @@ cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q,
     return CPE_OK;
 }
 
-cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas, const double* weight,
-                     double* q, double* dq, double* ddq, double* positions, double* meas_err, cpe_stats* stats) {
-    if (!h || !q_init || !meas || !weight || !q) return fail(CPE_BAD_ARG, "null argument");
-    if ((dq == nullptr) != (ddq == nullptr)) return fail(CPE_BAD_ARG, "dq and ddq must be given together");
-    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+// restart of an LM run from the current iterate (shutter-delay outer loop): every sequence runs again, its buffers stay
+__global__ void k_reset_status(SeqState* __restrict__ st, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { st[b].status = 0; st[b].al_pending = 0; }
+}
+
+// The LM loop of cpe_solve on the handle's workspace: cold start from q_init (device pointer) or, with q_init == nullptr, a restart from
+// the current iterate of every sequence.  sh: shutter-delay buffers (all null = off).
+static cpe_status lm_run(cpe_handle* h, int B, int N, const double* q_init, const double* meas, const double* weight, ShutterArgs sh) {
     const size_t F = (size_t)B * N;
-    if (F == 0) return CPE_OK;
-    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
-    HIPCHK(hipSetDevice(h->device));
-    cpe_status s = ensure_ws(h, B, N);
-    if (s != CPE_OK) return s;
     const DevModel& m = h->hm;
     const size_t Fw = F;   // buffers are laid out for exactly this call's F (strides use F)
-    hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q_init, h->qbuf);   // Euler q -> (q, alpha)
-    HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
-    HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
+    if (q_init) {
+        hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q_init, h->qbuf);   // Euler q -> (q, alpha)
+        HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
+        HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
+    } else hipLaunchKernelGGL(k_reset_status, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->st, B);
     LmParams prm;
     prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
     prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;
-    const size_t ldsn = lds_normal(m, h->gmm_k, h->gmm_dim);
+    const size_t ldsn = lds_normal(m, h->gmm_k, h->gmm_dim, sh.tau != nullptr);
     const bool lr = h->lr_window > 0;
     // One LM iteration = k_frame_normal (+ k_lr_band) on the evaluated buffer, then k_lm_step, for the first *n_act sequences listed
     // in `act` (device arrays; nullptr = all B).  The grids are sized for `slots` sequences; workgroups past *n_act leave at once.
@@ -772,7 +780,7 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
         const unsigned gf = (unsigned)((size_t)slots * N);
         prof_begin(h, 0);
         hipLaunchKernelGGL(k_frame_normal, dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
-                           h->costbuf, h->mu, h->gambuf, h->pri, act, n_act);
+                           h->costbuf, h->mu, h->gambuf, h->pri, act, n_act, sh);
         prof_end(h);
         if (lr) {
             prof_begin(h, 1);
@@ -781,10 +789,10 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
             prof_end(h);
         }
         prof_begin(h, 2);
-        if (h->pb == 3) hipLaunchKernelGGL(k_lm_step<3>, dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act);
-        else hipLaunchKernelGGL(k_lm_step<4>, dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act);
+        if (h->pb == 3) hipLaunchKernelGGL((k_lm_step<3, 0>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
+                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx);
+        else hipLaunchKernelGGL((k_lm_step<4, 0>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
+                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx);
         prof_end(h);
     };
     iterate(1, nullptr, nullptr, B);        // first evaluation and first step of every sequence
@@ -820,9 +828,17 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
         }
         slot = prev;
     }
+    return CPE_OK;
+}
+
+// outputs of a finished LM run (k_finalize) and the per-sequence statistics; `iters_extra[b]` iterations of earlier runs are added
+static cpe_status lm_finish(cpe_handle* h, int B, int N, const double* meas, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                            const double* tau, cpe_stats* stats, const std::vector<int>* iters_extra) {
+    const size_t F = (size_t)B * N;
+    const DevModel& m = h->hm;
     HIPCHK(hipMemsetAsync(h->cmax, 0, sizeof(double) * B, h->stream));
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, Fw, h->qbuf, meas, q, dq, ddq, positions, meas_err,
-                       reinterpret_cast<unsigned long long*>(h->cmax));
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)F), dim3(WAVE), lds_fk(m), h->stream, h->dm, h->st, N, F, h->qbuf, meas, q, dq, ddq, positions, meas_err,
+                       reinterpret_cast<unsigned long long*>(h->cmax), tau);
     HIPCHK(hipGetLastError());
     std::vector<double> hc(B);
     std::vector<SeqState> hs(B);
@@ -837,7 +853,7 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
         if (sb > worst) worst = sb;
         if (stats) {
             cpe_stats& o = stats[b];
-            o.status = sb; o.iterations = S.iters; o.lambda = S.lambda; o.max_constraint = hc[b];
+            o.status = sb; o.iterations = S.iters + (iters_extra ? (*iters_extra)[b] : 0); o.lambda = S.lambda; o.max_constraint = hc[b];
             o.max_bound_violation = S.maxviol; o.outer = S.outer; o._pad = 0;
             o.cost_meas = S.terms[0]; o.cost_model = S.terms[1]; o.cost_pose = S.terms[3]; o.cost_motion = S.terms[4];
             o.cost = h->opts.cost_scale * (S.terms[0] + S.terms[1] + S.terms[3] + S.terms[4]);
@@ -846,6 +862,131 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
     return worst;
 }
 
+cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas, const double* weight,
+                     double* q, double* dq, double* ddq, double* positions, double* meas_err, cpe_stats* stats) {
+    if (!h || !q_init || !meas || !weight || !q) return fail(CPE_BAD_ARG, "null argument");
+    if ((dq == nullptr) != (ddq == nullptr)) return fail(CPE_BAD_ARG, "dq and ddq must be given together");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    HIPCHK(hipSetDevice(h->device));
+    cpe_status s = ensure_ws(h, B, N);
+    if (s != CPE_OK) return s;
+    s = lm_run(h, B, N, q_init, meas, weight, ShutterArgs{nullptr, nullptr, nullptr});
+    if (s != CPE_OK) return s;
+    return lm_finish(h, B, N, meas, q, dq, ddq, positions, meas_err, nullptr, stats, nullptr);
+}
+
+// ---- shutter-delay estimation (include/cpe.h, cpe_solve_shutter) ------------------------------------------------------------------
+// Anderson mixing (memory AA_MEM) of the delay iteration tau <- tau + step(tau): the plain iteration contracts slowly where all delays move
+// together and the trajectory shifts in time to make up for it.  Host side, C - 1 unknowns per sequence.
+namespace {
+constexpr int AA_MEM = 4;
+struct Anderson {
+    int k = 0;
+    double X[AA_MEM + 1][CPE_MAX_CAMS], F[AA_MEM + 1][CPE_MAX_CAMS], fn_prev = 0;
+    void next(int n, const double* x, const double* f, double* xn) {
+        double fn = 0;
+        for (int i = 0; i < n; i++) fn += f[i] * f[i];
+        if (k > 0 && fn > fn_prev) k = 0;                             // residual grew: drop the history
+        fn_prev = fn;
+        const int slot = k % (AA_MEM + 1);
+        int mk = std::min(std::min(k, AA_MEM), n);
+        for (int i = 0; i < n; i++) { X[slot][i] = x[i]; F[slot][i] = f[i]; xn[i] = x[i] + f[i]; }
+        if (mk > 0) {
+            double dX[AA_MEM][CPE_MAX_CAMS], dF[AA_MEM][CPE_MAX_CAMS], Mn[AA_MEM][AA_MEM], r[AA_MEM], tr = 0;
+            for (int j = 0; j < mk; j++) {
+                const int s1 = (k - j) % (AA_MEM + 1), s0 = (k - j - 1) % (AA_MEM + 1);
+                for (int i = 0; i < n; i++) { dX[j][i] = X[s1][i] - X[s0][i]; dF[j][i] = F[s1][i] - F[s0][i]; }
+            }
+            for (int a = 0; a < mk; a++) {
+                for (int b = 0; b < mk; b++) { double v = 0; for (int i = 0; i < n; i++) v += dF[a][i] * dF[b][i]; Mn[a][b] = v; }
+                double v = 0; for (int i = 0; i < n; i++) v += dF[a][i] * f[i];
+                r[a] = v; tr += Mn[a][a];
+            }
+            for (int a = 0; a < mk; a++) Mn[a][a] += 1e-10 * tr / mk + 1e-300;
+            bool ok = true;
+            for (int j = 0; j < mk && ok; j++) {
+                double d = Mn[j][j];
+                for (int t = 0; t < j; t++) d -= Mn[j][t] * Mn[j][t];
+                if (!(d > 0)) { ok = false; break; }
+                d = sqrt(d); Mn[j][j] = d;
+                for (int i = j + 1; i < mk; i++) { double v = Mn[i][j]; for (int t = 0; t < j; t++) v -= Mn[i][t] * Mn[j][t]; Mn[i][j] = v / d; }
+            }
+            if (ok) {
+                for (int i = 0; i < mk; i++) { double v = r[i]; for (int t = 0; t < i; t++) v -= Mn[i][t] * r[t]; r[i] = v / Mn[i][i]; }
+                for (int i = mk - 1; i >= 0; i--) { double v = r[i]; for (int t = i + 1; t < mk; t++) v -= Mn[t][i] * r[t]; r[i] = v / Mn[i][i]; }
+                for (int j = 0; j < mk; j++) for (int i = 0; i < n; i++) xn[i] -= r[j] * (dX[j][i] + dF[j][i]);
+            }
+        }
+        k++;
+    }
+};
+}  // namespace
+
+cpe_status cpe_solve_shutter(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas, const double* weight, double tau_bound,
+                             int32_t max_rounds, double tol_tau, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                             double* tau_out, cpe_stats* stats, int32_t* rounds_out) {
+    if (!h || !q_init || !meas || !weight || !q || !tau_out) return fail(CPE_BAD_ARG, "null argument");
+    if ((dq == nullptr) != (ddq == nullptr)) return fail(CPE_BAD_ARG, "dq and ddq must be given together");
+    if (B < 0 || N < 0 || max_rounds < 1 || !(tau_bound > 0) || !(tol_tau > 0)) return fail(CPE_BAD_ARG, "bad size or tolerance");
+    const size_t F = (size_t)B * N;
+    if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    HIPCHK(hipSetDevice(h->device));
+    cpe_status s = ensure_ws(h, B, N);
+    if (s != CPE_OK) return s;
+    const int C = h->hm.C;
+    DevBuf gx, rcb, step;
+    HIPCHK(gx.alloc(2 * F * 6)); HIPCHK(rcb.alloc(2 * F * C * 9)); HIPCHK(step.alloc((size_t)B * C));
+    HIPCHK(hipMemsetAsync(tau_out, 0, sizeof(double) * B * C, h->stream));      // the first camera is the reference (tau = 0, acinoset_misc.py:274-275); the others start at 0
+    ShutterArgs sh{tau_out, gx.p, rcb.p};
+    std::vector<int> iters(B, 0);
+    std::vector<SeqState> hs(B);
+    std::vector<double> hstep((size_t)B * C), htau((size_t)B * C, 0.0);
+    std::vector<Anderson> mix(B);
+    std::vector<char> settled(B, 0);
+    int round = 0;
+    for (; round < max_rounds; round++) {
+        s = lm_run(h, B, N, round == 0 ? q_init : nullptr, meas, weight, sh);
+        if (s != CPE_OK) return s;
+        hipLaunchKernelGGL(k_shutter_step, dim3(B), dim3(WAVE), 0, h->stream, h->dm, h->st, N, F, h->qbuf, rcb.p, tau_out, step.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hs.data(), h->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hstep.data(), step.p, sizeof(double) * B * C, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        bool all = true, moved = false;
+        for (int b = 0; b < B; b++) {
+            iters[b] += hs[b].iters;
+            if (settled[b]) continue;                                 // its delays are a fixed point already (the trajectory solve above was a no-op restart)
+            double worst = 0.0, tn[CPE_MAX_CAMS];
+            for (int c = 1; c < C; c++) worst = std::max(worst, fabs(hstep[(size_t)b * C + c]));
+            if (worst == 0.0 || hs[b].status == 2) { settled[b] = 1; continue; }   // nothing to move (N < 3), or a numerical failure: leave its delays alone
+            mix[b].next(C, &htau[(size_t)b * C], &hstep[(size_t)b * C], tn);
+            // the plain step underestimates the distance to the fixed point by the contraction factor (the trajectory has not followed
+            // yet): the test is on the mixed update
+            worst = 0.0;
+            for (int c = 1; c < C; c++) {
+                const double v = std::min(tau_bound, std::max(-tau_bound, tn[c]));
+                worst = std::max(worst, fabs(v - htau[(size_t)b * C + c]));
+                htau[(size_t)b * C + c] = v;
+            }
+            moved = true;
+            if (worst < tol_tau) settled[b] = 1; else all = false;
+        }
+        if (moved) {
+            HIPCHK(hipMemcpyAsync(tau_out, htau.data(), sizeof(double) * B * C, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));                  // htau is pageable: the copy has left the host buffer only now
+        }
+        if (all) { if (moved) round++; break; }
+    }
+    // one more solve at the final delays (they moved after the last one if max_rounds ran out; otherwise a restart that stops at once)
+    s = lm_run(h, B, N, nullptr, meas, weight, sh);
+    if (s != CPE_OK) return s;
+    if (rounds_out) *rounds_out = round;
+    return lm_finish(h, B, N, meas, q, dq, ddq, positions, meas_err, tau_out, stats, &iters);
+}
 
 // ---- physics-based trajectory model (include/cpe.h, cpe_solve_kinetic) -------------------------------------------------------------
 void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kinetic_dataset) {
@@ -1110,11 +1251,6 @@ cpe_status cpe_debug_lm_stamps(unsigned long long* out16) {
 #endif
 
 // ---- host-pointer wrappers: stage through HBM (PCIe-inclusive; never the benchmarked path) -------------
-struct DevBuf {
-    double* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(double) * (n ? n : 1)); }
-};
 
 cpe_status cpe_eval_resjac_host(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
                                 double* r, double* J, double* eps, double* cost) {

@@ -276,6 +276,7 @@ class CheetahEstimator:
     tables: object = None
     device: int = 0
     opt_time_s: float = 0.0
+    shutter_delay: Optional[np.ndarray] = None   # [C] seconds, set by estimate_kinematics when enable_shutter_delay_estimation
     costs: Dict[str, float] = field(default_factory=dict)
     result: Optional[dict] = None
     com_pos: Optional[np.ndarray] = None
@@ -398,7 +399,18 @@ class CheetahEstimator:
         pos = res["positions"][0]
         hw = _lib.Handle(self.skeleton, all_cams, device=self.device)          # every camera of the scene, also for monocular runs
         try:
-            uv_all = hw.reproject_host(pos[None])[0]                           # [N, C, 24, 2] on the GPU (cpe_reproject)
+            delays = self.shutter_delay
+            if delays is None:
+                uv_all = hw.reproject_host(pos[None])[0]                       # [N, C, 24, 2] on the GPU (cpe_reproject)
+            else:
+                # positions_arr[c] = markers + q'_base tau_c + q''_base tau_c^2 (acinoset_opt.py:342-352), from node 2 on as the solve models it
+                shift = np.zeros((scene.n_cams,) + pos.shape)
+                for c in range(scene.n_cams):
+                    d3 = dq[:, 0:3] * delays[c] + ddq[:, 0:3] * delays[c] ** 2
+                    d3[:2] = 0.0
+                    shift[c] = pos + d3[:, None, :]
+                uv_c = hw.reproject_host(shift)                                # [C, N, C, 24, 2]: camera c reads its own displaced copy
+                uv_all = np.stack([uv_c[c, :, c] for c in range(scene.n_cams)], axis=1)
         finally:
             hw.close()
         for i in range(scene.n_cams):
@@ -426,8 +438,10 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
                     device: int = 0) -> CheetahEstimator:
     """Same signature and meaning as acinoset_opt.init_trajectory (acinoset_opt.py:413-536).  `solver_path`
     (the IPOPT binary of the reference) is accepted and ignored."""
-    if shutter_delay_estimation or hand_labeled_data:
-        raise NotImplementedError("shutter-delay estimation (SURVEY 8f-4, second half) and hand-labelled data are not built")
+    if hand_labeled_data:
+        raise NotImplementedError("hand-labelled data (dlc_hand_labeled/*.h5, squared loss) is not built; no stored run of the reference uses it")
+    if shutter_delay_estimation and enable_ppm and not monocular_enable:
+        raise NotImplementedError("shutter delays together with pairwise predictions: the three measurement slices of a camera would share one delay")
     if cheetah_name not in ("jules", "phantom", "shiraz", "arabia"):
         cheetah_name = "acinoset"                                   # acinoset_opt.py:455-456
     model_name = f"{cheetah_name}-02" if kinetic_dataset else cheetah_name
@@ -510,7 +524,13 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
     h = _lib.Handle(sk, est.cams, opts, pri, device=est.device)
     try:
         t0 = time()
-        res = h.solve_host(q_init[None], est.meas[None], est.weight[None])
+        if params.enable_shutter_delay_estimation and scene.cam_idx is None:
+            # m.shutter_delay, bounds +-hm0, camera 1 fixed (acinoset_misc.py:182-183, 273-275)
+            res = h.solve_shutter_host(q_init[None], est.meas[None], est.weight[None], opts.h, max_rounds=20, tol_tau=1e-5)
+            est.shutter_delay = res["tau"][0]
+        else:
+            res = h.solve_host(q_init[None], est.meas[None], est.weight[None])
+            est.shutter_delay = None
         est.opt_time_s = time() - t0
         import torch
         dev = torch.device("cuda", est.device)
@@ -527,6 +547,8 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
     if solver_output:
         print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- model: {st.cost_model}\n-- pose: {st.cost_pose}\n-- motion: {st.cost_motion}\n"
               f"status {st.status}, {st.iterations} LM iterations, {est.opt_time_s:.3f} s")
+        if est.shutter_delay is not None:
+            print("Shutter delay estimation:", [float(v) for v in est.shutter_delay])           # acinoset_opt.py:397-398
     ok = st.status == abi.OK
     if ok:
         fname = "fte_kinematic"
@@ -606,6 +628,8 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
                                   "the physics-based reconstruction of run_dataset.py uses joint_estimation=True")
     if not use_2d_reprojections:
         raise NotImplementedError("the 3D kinematic cost (use_2d_reprojections=False) is not built")
+    if params.enable_shutter_delay_estimation and scene.cam_idx is None:
+        raise NotImplementedError("shutter delays are estimated by estimate_kinematics only (cpe_solve_shutter); not inside the physics-based model")
     data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, est.data_path)
     mono = scene.cam_idx is not None and init_prev_kinematic_solution
     fte = load_result_pickle(os.path.join(data_dir, f"fte_kinematic_{scene.cam_idx}" if mono else "fte_kinematic", "fte.pickle"))

@@ -222,9 +222,11 @@ def truth_trajectory(sk: abi.Skeleton, N: int, fps: float, rng: np.random.Genera
 
 def make_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0, seed: int = 1234,
                noise_px: float = 2.0, outlier_frac: float = 0.10, init_noise: float = 0.05,
-               dlc_thresh: float = 0.5, kinetic_dataset: bool = False, wide_limbs: bool = False):
+               dlc_thresh: float = 0.5, kinetic_dataset: bool = False, wide_limbs: bool = False, shutter_delay=None):
     """B independent sequences (sequence b uses seed + b).  Returns dict of C-contiguous fp64 arrays:
-    q_true, q_init [B,N,nq]; meas [B,N,C,L,2]; weight [B,N,C,L]."""
+    q_true, q_init [B,N,nq]; meas [B,N,C,L,2]; weight [B,N,C,L].
+    shutter_delay [C] (seconds): camera c sees the markers displaced by x' tau_c + x'' tau_c^2 of the base position
+    (acinoset_misc.py:283-285), backward differences, from node 2 on as cpe_solve_shutter models it."""
     C, L, nq = len(cams), sk.n_markers, sk.nq
     q_true = np.empty((B, N, nq)); q_init = np.zeros((B, N, nq))
     meas = np.empty((B, N, C, L, 2)); weight = np.empty((B, N, C, L))
@@ -235,7 +237,13 @@ def make_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0,
         q_true[b] = qt
         pos, _ = fk_numpy(sk, qt)
         for c in range(C):
-            uv, z = project_numpy(cams[c], pos)
+            pc = pos
+            if shutter_delay is not None and N > 2:
+                ta, x = float(shutter_delay[c]), qt[:, 0:3]
+                d = np.zeros((N, 3))
+                d[2:] = (x[2:] - x[1:-1]) * fps * ta + (x[2:] - 2 * x[1:-1] + x[:-2]) * fps * fps * ta * ta
+                pc = pos + d[:, None, :]
+            uv, z = project_numpy(cams[c], pc)
             uv = uv + rng.normal(0, noise_px, uv.shape)
             out = rng.random((N, L)) < outlier_frac
             uv[out] = np.stack([rng.uniform(0, IMG_W, out.sum()), rng.uniform(0, IMG_H, out.sum())], axis=-1)

@@ -216,6 +216,20 @@ cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, 
                      const double* weight, double* q, double* dq, double* ddq, double* positions,
                      double* meas_err, cpe_stats* stats);
 
+/* ---- shutter-delay estimation (`shutter_delay_estimation=True`, acinoset_misc.py:179-183, :274-288; run_dataset.py:1323) -----------
+ * The reference adds one unknown delay tau_c per camera (camera 1 fixed to 0, |tau_c| <= h) and lets camera c see every marker displaced by
+ * q'_base tau_c + q''_base tau_c^2 (implicit-Euler velocity and acceleration of the base position).  Solved here by block-coordinate descent on
+ * the reference's objective: cpe_solve's LM with the delays fixed (exact gradient, including the parts that reach frames n-1 and n-2 through q',
+ * q''; curvature inside the frame exact, cross-frame curvature blocks left out of the Gauss-Newton model), then one Newton step per delay with
+ * the trajectory fixed; the sequence of delay vectors is accelerated by Anderson mixing (memory 4, host side, per sequence: the plain alternation
+ * contracts slowly where all delays move together and the trajectory shifts in time), clamped to +-tau_bound; repeated until no delay moves by
+ * more than tol_tau (<= max_rounds), then a last trajectory solve.
+ * Deviation: the displacement acts from node 2 on (q'_0 and q''_0 are free variables of the reference's collocation: its first two nodes can
+ * absorb any displacement).  Device pointers; tau [B][C] (output; tau[.][0] = 0); stats HOST; rounds (HOST, optional) = delay updates done. */
+cpe_status cpe_solve_shutter(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas, const double* weight, double tau_bound,
+                             int32_t max_rounds, double tol_tau, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                             double* tau, cpe_stats* stats, int32_t* rounds);
+
 /* host-pointer convenience wrappers of cpe_eval_resjac / cpe_solve above (same reference counterparts: acinoset_misc.py:269-288,
  * acinoset_opt.py:611-617); they stage through HBM, so their rates are PCIe-inclusive */
 cpe_status cpe_eval_resjac_host(cpe_handle* h, int32_t B, int32_t N, const double* q, const double* meas,

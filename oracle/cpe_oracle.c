@@ -480,6 +480,8 @@ struct kin_s;
 typedef struct {
     const cpe_skeleton* s; const cpe_camera* cams; int C; const cpe_options* o; const cpe_priors* pr;
     struct kin_s* kin;            /* physics-based model (cpo_solve_kinetic), NULL for the kinematic models */
+    const double* tau;            /* shutter delays per camera (cpo_solve_shutter), NULL = off */
+    double* rcb;                  /* [N][C][9]: per camera sum_l G^T rho' w (3) and sum_l G^T cw G (6) of the last evaluation with gradient */
     int nq, nu, indep[CPE_MAX_NQ], dep[CPE_MAX_NQ], u_of_q[CPE_MAX_NQ];
     int nrev, ns;                 /* revolute (leg) links, state size nq + nrev */
     int rev_joint[CPE_MAX_JOINTS];/* joint index of revolute r */
@@ -488,7 +490,7 @@ typedef struct {
 } ctx_t;
 
 static void ctx_init(ctx_t* x, const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr) {
-    x->s = s; x->cams = cams; x->C = C; x->o = o; x->pr = pr; x->nq = NQ(s); x->kin = NULL;
+    x->s = s; x->cams = cams; x->C = C; x->o = o; x->pr = pr; x->nq = NQ(s); x->kin = NULL; x->tau = NULL; x->rcb = NULL;
     x->nu = cpo_split_dofs(s, x->indep, x->dep);
     for (int p = 0; p < x->nq; p++) x->u_of_q[p] = -1;
     for (int k = 0; k < x->nu; k++) { x->u_of_q[x->indep[k]] = k; x->rev_of_u[k] = -1; }
@@ -578,7 +580,9 @@ static void state_jacobian(const ctx_t* x, const double* st, double* Zp) {
 
 /* cost terms for one frame; returns meas cost, *cb bound-penalty cost, *cp pose-prior cost */
 static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* [nq][nu], needed iff g */, const double* meas, const double* weight,
-                          const double* mu, double* g, double* Bm, double* cb, double* cp, double* viol_out) {
+                          const double* mu, double* g, double* Bm, double* cb, double* cp, double* viol_out,
+                          const double* x1, const double* x2 /* base positions of frames n-1, n-2 (shutter delay, n >= 2), or NULL */,
+                          double* gx /* [6] gradient parts for the base position of frames n-1, n-2 */, double* rc9 /* [C][9] */) {
     const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu, L = s->n_markers;
     double pos[CPE_MAX_MARKERS * 3];
     double* dpos = NULL; const double* Z = Zp; double* dpu = NULL;
@@ -598,12 +602,21 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
     double fm = 0, rho0[3];
     double Ju[CPE_NX + 8];
     cpo_loss(0.0, x->o->loss_a, x->o->loss_b, x->o->loss_c, rho0);
-    for (int c = 0; c < x->C; c++)
+    if (gx) for (int i = 0; i < 6; i++) gx[i] = 0;
+    if (rc9) for (int i = 0; i < 9 * x->C; i++) rc9[i] = 0;
+    for (int c = 0; c < x->C; c++) {
+        /* shutter delay (acinoset_misc.py:283-285): camera c sees the markers displaced by q'_base tau_c + q''_base tau_c^2 = alpha x_n + beta x_n-1 + gamma x_n-2 */
+        double al = 0, be = 0, ga = 0, sft[3] = {0, 0, 0};
+        if (x->tau && x1) {
+            double ta = x->tau[c], ih = 1.0 / x->o->h;
+            al = ta * ih + ta * ta * ih * ih; be = -ta * ih - 2 * ta * ta * ih * ih; ga = ta * ta * ih * ih;
+            for (int d = 0; d < 3; d++) sft[d] = al * qn[d] + be * x1[d] + ga * x2[d];
+        }
         for (int l = 0; l < L; l++) {
             double w = x->cams[c].mult * weight[c * L + l];
             if (w == 0.0) { fm += 2 * rho0[0]; continue; } /* the reference still adds rho(0) for both coordinates */
-            double uv[2], G[6];
-            cpo_project(&x->cams[c], pos + 3 * l, uv, want ? G : NULL);
+            double uv[2], G[6], pt[3] = {pos[3 * l] + sft[0], pos[3 * l + 1] + sft[1], pos[3 * l + 2] + sft[2]};
+            cpo_project(&x->cams[c], pt, uv, want ? G : NULL);
             for (int d = 0; d < 2; d++) {
                 double e = uv[d] - meas[(c * L + l) * 2 + d], sres = w * e, Lo[3];
                 cpo_loss(sres, x->o->loss_a, x->o->loss_b, x->o->loss_c, Lo);
@@ -611,13 +624,22 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
                 if (!want) continue;
                 double gs = Lo[1] * w, cw = curv_weight(Lo, sres, x->o->curvature) * w * w;
                 for (int k = 0; k < nu; k++)
-                    Ju[k] = G[3 * d] * dpu[(3 * l) * nu + k] + G[3 * d + 1] * dpu[(3 * l + 1) * nu + k] + G[3 * d + 2] * dpu[(3 * l + 2) * nu + k];
+                    Ju[k] = G[3 * d] * dpu[(3 * l) * nu + k] + G[3 * d + 1] * dpu[(3 * l + 1) * nu + k] + G[3 * d + 2] * dpu[(3 * l + 2) * nu + k]
+                            + (k < 3 ? al * G[3 * d + k] : 0.0);            /* d P / d x_n = (1 + alpha) I: reduced coordinates 0..2 are the base position */
                 for (int k = 0; k < nu; k++) {
                     g[k] += gs * Ju[k];
                     if (Ju[k] != 0.0) for (int m = 0; m < nu; m++) Bm[k * nu + m] += cw * Ju[k] * Ju[m];
                 }
+                if (gx) for (int j = 0; j < 3; j++) { gx[j] += be * gs * G[3 * d + j]; gx[3 + j] += ga * gs * G[3 * d + j]; }
+                if (rc9) {
+                    double* r9 = rc9 + 9 * c;
+                    for (int j = 0; j < 3; j++) r9[j] += gs * G[3 * d + j];
+                    r9[3] += cw * G[3 * d] * G[3 * d]; r9[4] += cw * G[3 * d] * G[3 * d + 1]; r9[5] += cw * G[3 * d] * G[3 * d + 2];
+                    r9[6] += cw * G[3 * d + 1] * G[3 * d + 1]; r9[7] += cw * G[3 * d + 1] * G[3 * d + 2]; r9[8] += cw * G[3 * d + 2] * G[3 * d + 2];
+                }
             }
         }
+    }
     /* angle bounds (cheetah.py:306-352) by an augmented Lagrangian: per bound and side a multiplier mu >= 0,
      * psi = (max(0, mu + kappa*viol_signed)^2 - mu^2) / (2 kappa); mu == NULL means all multipliers zero */
     double fb = 0, vmax = 0;
@@ -738,8 +760,12 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
         double* Zn = g ? Zall + (size_t)n * nq * nu : NULL;
         if (g) state_jacobian(x, sn, Zn);
         double cb, cp, vm;
+        double gx6[6];
+        int sd = x->tau != NULL && n >= 2;                       /* the displacement acts from node 2 on (include/cpe.h, cpe_solve_shutter) */
         double fm = frame_terms(x, sn, Zn, meas + (size_t)n * C * L * 2, weight + (size_t)n * C * L,
-                                mu ? mu + (size_t)n * s->n_bounds * 2 : NULL, g ? gB : NULL, g ? gB + nu : NULL, &cb, &cp, &vm);
+                                mu ? mu + (size_t)n * s->n_bounds * 2 : NULL, g ? gB : NULL, g ? gB + nu : NULL, &cb, &cp, &vm,
+                                sd ? sn - ns : NULL, sd ? sn - 2 * ns : NULL, (g && sd) ? gx6 : NULL, (g && x->rcb) ? x->rcb + (size_t)n * C * 9 : NULL);
+        if (g && sd) for (int j = 0; j < 3; j++) { g[(n - 1) * nu + j] += gx6[j]; g[(n - 2) * nu + j] += gx6[3 + j]; }
         ct->meas += fm; ct->bound += cb; ct->pose += cp;
         if (vm > ct->maxviol) ct->maxviol = vm;
         if (g) {
@@ -838,12 +864,24 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
 
 /* Levenberg-Marquardt over the whole trajectory in reduced coordinates (stands where IPOPT is called,
  * acinoset_opt.py:611-617).  Same algorithm as the HIP product (DESIGN.md "Solver"). */
+typedef struct { const double* tau; double* rcb; double* mu_keep; } shutter_t;
+static cpe_status solve_impl2(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
+                              const cpe_priors* pr, int N, const double* q_init, const double* meas,
+                              const double* weight, double* q, double* dq, double* ddq, double* positions,
+                              double* meas_err, cpe_stats* st, kin_t* K, const shutter_t* SH);
 static cpe_status solve_impl(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
                              const cpe_priors* pr, int N, const double* q_init, const double* meas,
                              const double* weight, double* q, double* dq, double* ddq, double* positions,
                              double* meas_err, cpe_stats* st, kin_t* K) {
+    return solve_impl2(s, cams, C, o, pr, N, q_init, meas, weight, q, dq, ddq, positions, meas_err, st, K, NULL);
+}
+static cpe_status solve_impl2(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
+                              const cpe_priors* pr, int N, const double* q_init, const double* meas,
+                              const double* weight, double* q, double* dq, double* ddq, double* positions,
+                              double* meas_err, cpe_stats* st, kin_t* K, const shutter_t* SH) {
     ctx_t x; ctx_init(&x, s, cams, C, o, pr);
     x.kin = K;
+    if (SH) { x.tau = SH->tau; x.rcb = SH->rcb; }
     int nq = x.nq, nu = x.nu, ns = x.ns, L = s->n_markers;
     int bw = 3; if (pr && pr->lr_window > bw) bw = pr->lr_window;
     int kd = (bw + 1) * nu - 1, n_tot = N * nu;
@@ -857,7 +895,7 @@ static cpe_status solve_impl(const cpe_skeleton* s, const cpe_camera* cams, int 
     double* dl = (double*)malloc(sizeof(double) * n_tot);
     for (int n = 0; n < N; n++) state_from_q(&x, q_init + (size_t)n * nq, qc + (size_t)n * ns);
     costs_t cc, ctr;
-    double* mu = (double*)calloc((size_t)N * s->n_bounds * 2 + 1, sizeof(double));
+    double* mu = (SH && SH->mu_keep) ? SH->mu_keep : (double*)calloc((size_t)N * s->n_bounds * 2 + 1, sizeof(double));
     seq_eval(&x, N, kd, qc, meas, weight, mu, &cc, g, ab);
     const double NU0 = 8.0;   /* first rejection multiplies lambda by 8, then 16, 32, ... (Nielsen's rule starts at 2: measured 6 % more iterations) */
     double lam = o->lambda0, nu_f = NU0;
@@ -941,7 +979,12 @@ static cpe_status solve_impl(const cpe_skeleton* s, const cpe_camera* cams, int 
         for (int i = 0; i < nc; i++) if (fabs(cv[i]) > maxc) maxc = fabs(cv[i]);
         if (meas_err)
             for (int c = 0; c < C; c++) for (int l = 0; l < L; l++) {
-                double uv[2]; cpo_project(&cams[c], pos + 3 * l, uv, NULL);
+                double uv[2], pt[3] = {pos[3 * l], pos[3 * l + 1], pos[3 * l + 2]};
+                if (x.tau && n >= 2) {
+                    double ta = x.tau[c], ih = 1.0 / o->h, al = ta * ih + ta * ta * ih * ih, be = -ta * ih - 2 * ta * ta * ih * ih, ga = ta * ta * ih * ih;
+                    for (int d = 0; d < 3; d++) pt[d] += al * q[(size_t)n * nq + d] + be * q[(size_t)(n - 1) * nq + d] + ga * q[(size_t)(n - 2) * nq + d];
+                }
+                cpo_project(&cams[c], pt, uv, NULL);
                 size_t b = ((size_t)(n * C + c) * L + l) * 2;
                 meas_err[b] = uv[0] - meas[b]; meas_err[b + 1] = uv[1] - meas[b + 1];
             }
@@ -952,8 +995,105 @@ static cpe_status solve_impl(const cpe_skeleton* s, const cpe_camera* cams, int 
         st->cost_meas = cc.meas; st->cost_model = cc.model; st->cost_pose = cc.pose; st->cost_motion = cc.motion;
         st->cost = o->cost_scale * (cc.meas + cc.model + cc.pose + cc.motion);
     }
-    free(qc); free(qt); free(g); free(ab); free(abf); free(dl); free(mu); if (abm) free(abm);
+    free(qc); free(qt); free(g); free(ab); free(abf); free(dl); if (!(SH && SH->mu_keep)) free(mu); if (abm) free(abm);
     return status;
+}
+
+/* Anderson mixing of the delay fixed-point iteration tau <- tau + step(tau) (memory CPO_AA_MEM): the plain iteration contracts
+ * slowly in the direction where all delays move together and the trajectory shifts in time to make up for it */
+#define CPO_AA_MEM 4
+typedef struct { int k; double X[CPO_AA_MEM + 1][CPE_MAX_CAMS], F[CPO_AA_MEM + 1][CPE_MAX_CAMS], fn_prev; } anderson_t;
+static void anderson_next(anderson_t* A, int n, const double* x, const double* f, double* xn) {
+    double fn = 0;
+    for (int i = 0; i < n; i++) fn += f[i] * f[i];
+    if (A->k > 0 && fn > A->fn_prev) A->k = 0;                      /* residual grew: drop the history */
+    A->fn_prev = fn;
+    int slot = A->k % (CPO_AA_MEM + 1), mk = A->k < CPO_AA_MEM ? A->k : CPO_AA_MEM;
+    for (int i = 0; i < n; i++) { A->X[slot][i] = x[i]; A->F[slot][i] = f[i]; }
+    for (int i = 0; i < n; i++) xn[i] = x[i] + f[i];
+    if (mk > n) mk = n;
+    if (mk > 0) {
+        double dX[CPO_AA_MEM][CPE_MAX_CAMS], dF[CPO_AA_MEM][CPE_MAX_CAMS], M[CPO_AA_MEM][CPO_AA_MEM], r[CPO_AA_MEM], tr = 0;
+        for (int j = 0; j < mk; j++) {
+            int s1 = (A->k - j) % (CPO_AA_MEM + 1), s0 = (A->k - j - 1) % (CPO_AA_MEM + 1);
+            for (int i = 0; i < n; i++) { dX[j][i] = A->X[s1][i] - A->X[s0][i]; dF[j][i] = A->F[s1][i] - A->F[s0][i]; }
+        }
+        for (int a = 0; a < mk; a++) {
+            for (int b = 0; b < mk; b++) { double v = 0; for (int i = 0; i < n; i++) v += dF[a][i] * dF[b][i]; M[a][b] = v; }
+            double v = 0; for (int i = 0; i < n; i++) v += dF[a][i] * f[i];
+            r[a] = v; tr += M[a][a];
+        }
+        for (int a = 0; a < mk; a++) M[a][a] += 1e-10 * tr / mk + 1e-300;
+        int ok = 1;                                                  /* Cholesky of the mk x mk normal matrix */
+        for (int j = 0; j < mk && ok; j++) {
+            double d = M[j][j];
+            for (int k = 0; k < j; k++) d -= M[j][k] * M[j][k];
+            if (!(d > 0)) { ok = 0; break; }
+            d = sqrt(d); M[j][j] = d;
+            for (int i = j + 1; i < mk; i++) { double v = M[i][j]; for (int k = 0; k < j; k++) v -= M[i][k] * M[j][k]; M[i][j] = v / d; }
+        }
+        if (ok) {
+            for (int i = 0; i < mk; i++) { double v = r[i]; for (int k = 0; k < i; k++) v -= M[i][k] * r[k]; r[i] = v / M[i][i]; }
+            for (int i = mk - 1; i >= 0; i--) { double v = r[i]; for (int k = i + 1; k < mk; k++) v -= M[k][i] * r[k]; r[i] = v / M[i][i]; }
+            for (int j = 0; j < mk; j++) for (int i = 0; i < n; i++) xn[i] -= r[j] * (dX[j][i] + dF[j][i]);
+        }
+    }
+    A->k++;
+}
+
+/* shutter-delay estimation (include/cpe.h, cpe_solve_shutter): trajectory solve with the delays fixed, then one Newton step per
+ * delay with the trajectory fixed (same sums as k_shutter_step), the sequence of delays accelerated by Anderson mixing */
+cpe_status cpo_solve_shutter(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr, int N,
+                             const double* q_init, const double* meas, const double* weight, double tau_bound, int max_rounds, double tol_tau,
+                             double* q, double* dq, double* ddq, double* positions, double* meas_err, double* tau, cpe_stats* st, int* rounds_out) {
+    int nq = NQ(s), iters = 0, round = 0;
+    double* rcb = (double*)calloc((size_t)N * C * 9 + 1, sizeof(double));
+    double* mu = (double*)calloc((size_t)N * s->n_bounds * 2 + 1, sizeof(double));
+    double* qi = (double*)malloc(sizeof(double) * (size_t)N * nq);
+    memcpy(qi, q_init, sizeof(double) * (size_t)N * nq);
+    for (int c = 0; c < C; c++) tau[c] = 0;
+    shutter_t SH = {tau, rcb, mu};
+    anderson_t AA; AA.k = 0; AA.fn_prev = 0;
+    cpe_status rc = CPE_OK;
+    for (; round < max_rounds; round++) {
+        rc = solve_impl2(s, cams, C, o, pr, N, qi, meas, weight, q, NULL, NULL, NULL, NULL, st, NULL, &SH);
+        iters += st->iterations;
+        memcpy(qi, q, sizeof(double) * (size_t)N * nq);
+        double worst = 0, ih = 1.0 / o->h, step[CPE_MAX_CAMS], tn[CPE_MAX_CAMS];
+        step[0] = 0;
+        for (int c = 1; c < C; c++) {
+            double ta = tau[c], g = 0, hh = 0;
+            for (int n = 2; n < N; n++) {
+                const double* r = rcb + ((size_t)n * C + c) * 9;
+                double t3[3];
+                for (int d = 0; d < 3; d++) {
+                    double x0 = q[(size_t)n * nq + d], x1 = q[(size_t)(n - 1) * nq + d], x2 = q[(size_t)(n - 2) * nq + d];
+                    t3[d] = (x0 - x1) * ih + 2 * ta * (x0 - 2 * x1 + x2) * ih * ih;
+                }
+                g += t3[0] * r[0] + t3[1] * r[1] + t3[2] * r[2];
+                hh += t3[0] * (r[3] * t3[0] + r[4] * t3[1] + r[5] * t3[2]) + t3[1] * (r[4] * t3[0] + r[6] * t3[1] + r[7] * t3[2]) + t3[2] * (r[5] * t3[0] + r[7] * t3[1] + r[8] * t3[2]);
+            }
+            step[c] = hh > 0 ? -g / hh : 0.0;
+            if (fabs(step[c]) > worst) worst = fabs(step[c]);
+            if (getenv("CPO_DEBUG")) fprintf(stderr, "round %d cam %d tau %.6g g %.6g h %.6g\n", round, c, ta, g, hh);
+        }
+        if (worst == 0.0) break;                                       /* no node carries a displacement (N < 3), or nothing to move */
+        anderson_next(&AA, C, tau, step, tn);
+        /* the plain step underestimates the distance to the fixed point by the contraction factor (the trajectory has not followed yet):
+         * the test is on the mixed update */
+        worst = 0;
+        for (int c = 1; c < C; c++) {
+            double v = tn[c] > tau_bound ? tau_bound : (tn[c] < -tau_bound ? -tau_bound : tn[c]);
+            if (fabs(v - tau[c]) > worst) worst = fabs(v - tau[c]);
+            tau[c] = v;
+        }
+        if (worst < tol_tau) { round++; break; }
+    }
+    rc = solve_impl2(s, cams, C, o, pr, N, qi, meas, weight, q, dq, ddq, positions, meas_err, st, NULL, &SH);
+    st->iterations += iters;
+    if (rounds_out) *rounds_out = round;
+    free(rcb); free(mu); free(qi);
+    return rc;
 }
 
 cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
@@ -1128,6 +1268,34 @@ double cpo_objective(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     return ct.total;
 }
 
+/* cpo_objective with per-camera shutter delays: f, reduced gradient g [N*nu] and d f / d tau [C] (tests: finite differences) */
+double cpo_objective_shutter(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr, int N, double* q,
+                             const double* meas, const double* weight, const double* tau, double* g, double* gtau) {
+    ctx_t x; ctx_init(&x, s, cams, C, o, pr);
+    int bw = 3; if (pr && pr->lr_window > bw) bw = pr->lr_window;
+    int kd = (bw + 1) * x.nu - 1;
+    costs_t ct;
+    double* st = (double*)malloc(sizeof(double) * (size_t)N * x.ns);
+    double* ab = g ? (double*)malloc(sizeof(double) * (size_t)N * x.nu * (kd + 1)) : NULL;
+    double* rcb = g ? (double*)calloc((size_t)N * C * 9 + 1, sizeof(double)) : NULL;
+    x.tau = tau; x.rcb = rcb;
+    for (int n = 0; n < N; n++) state_from_q(&x, q + (size_t)n * x.nq, st + (size_t)n * x.ns);
+    seq_eval(&x, N, kd, st, meas, weight, NULL, &ct, g, ab);
+    for (int n = 0; n < N; n++) memcpy(q + (size_t)n * x.nq, st + (size_t)n * x.ns, sizeof(double) * x.nq);
+    if (g && gtau)
+        for (int c = 0; c < C; c++) {
+            double acc = 0, ih = 1.0 / o->h;
+            for (int n = 2; n < N; n++)
+                for (int d = 0; d < 3; d++) {
+                    double x0 = st[(size_t)n * x.ns + d], x1 = st[(size_t)(n - 1) * x.ns + d], x2 = st[(size_t)(n - 2) * x.ns + d];
+                    acc += ((x0 - x1) * ih + 2 * tau[c] * (x0 - 2 * x1 + x2) * ih * ih) * rcb[((size_t)n * C + c) * 9 + d];
+                }
+            gtau[c] = acc;
+        }
+    free(st); if (ab) free(ab); if (rcb) free(rcb);
+    return ct.total;
+}
+
 /* per-frame terms in reduced coordinates at Euler q_n (made consistent first): measurement + bounds (+ pose prior)
  * cost[3] = {meas, bound, pose}; g[nu]; B[nu][nu]; Gam[nq][nu] = d Euler / d coordinates (optional) */
 void cpo_frame_normal(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
@@ -1138,7 +1306,7 @@ void cpo_frame_normal(const cpe_skeleton* s, const cpe_camera* cams, int C, cons
     double* Zp = (double*)malloc(sizeof(double) * x.nq * x.nu);
     state_jacobian(&x, st, Zp);
     double cb, cp, vm;
-    cost[0] = frame_terms(&x, st, Zp, meas, weight, NULL, g, Bm, &cb, &cp, &vm);
+    cost[0] = frame_terms(&x, st, Zp, meas, weight, NULL, g, Bm, &cb, &cp, &vm, NULL, NULL, NULL, NULL);
     cost[1] = cb; cost[2] = cp;
     memcpy(qn, st, sizeof(double) * x.nq);
     if (Zout) memcpy(Zout, Zp, sizeof(double) * x.nq * x.nu);

@@ -240,6 +240,34 @@ def solve(sk, cams, opts, priors, q_init, meas, weight):
     return dict(q=q, dq=dq, ddq=ddq, positions=pos, meas_err=me, stats=st)
 
 
+def objective_shutter(sk, cams, opts, priors, q, meas, weight, tau, want_grad=False):
+    """objective with shutter delays tau [C]: f, g [N*nu] (reduced coordinates), d f / d tau [C], q made consistent"""
+    q, meas, weight, tau = _c(q).copy(), _c(meas), _c(weight), _c(tau)
+    N, Cn, L = weight.shape
+    g = np.zeros(N * abi.NX) if want_grad else None
+    gt = np.zeros(Cn) if want_grad else None
+    fn = lib().cpo_objective_shutter
+    fn.restype = C.c_double
+    f = fn(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, N, _p(q), _p(meas), _p(weight), _p(tau),
+           _p(g), _p(gt))
+    return f, g, gt, q
+
+
+def solve_shutter(sk, cams, opts, priors, q_init, meas, weight, tau_bound, max_rounds=8, tol_tau=1e-6):
+    """One sequence with per-camera shutter delays (cpo_solve_shutter).  Returns solve()'s dict + tau [C], rounds."""
+    q_init, meas, weight = _c(q_init), _c(meas), _c(weight)
+    N, Cn, L = weight.shape
+    q = np.empty_like(q_init); dq = np.empty_like(q_init); ddq = np.empty_like(q_init)
+    pos = np.empty((N, L, 3)); me = np.empty((N, Cn, L, 2)); tau = np.zeros(Cn)
+    st = abi.Stats(); rounds = C.c_int32(0)
+    f = lib().cpo_solve_shutter
+    f.restype = C.c_int32
+    f(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, N, _p(q_init), _p(meas), _p(weight),
+      C.c_double(tau_bound), C.c_int32(max_rounds), C.c_double(tol_tau), _p(q), _p(dq), _p(ddq), _p(pos), _p(me), _p(tau), C.byref(st),
+      C.byref(rounds))
+    return dict(q=q, dq=dq, ddq=ddq, positions=pos, meas_err=me, stats=st, tau=tau, rounds=rounds.value)
+
+
 def move_coordinate(sk, q, n, k, d):
     """copy of q[N,nq] with reduced coordinate k of frame n moved by d (leg coordinates are the rotation
     angles alpha_c about the body's y axis, trunk coordinates are Euler angles / translations)"""

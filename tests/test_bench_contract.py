@@ -30,9 +30,12 @@ def test_algorithmic_bytes_and_traffic_record():
     assert 2.5e5 < b.lm_flops_per_frame_iteration() < 3.5e5
     assert b.HBM_PEAK == 8.0e12
     t = b.pmc_traffic(2048, 200, 6, 25)
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_resjac.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:      # the newest round's record wins (bounded workload: scaled per frame)
         rec = json.load(f)
-    assert abs(t - rec["hbm_bytes_per_launch"]["total_corrected"]) < 1e-6 * t and 0.9 < t / (33360 * 2048 * 200) < 1.1
+    per_frame = rec["kernels"]["k_resjac<false"]["total_corrected"] / rec["frames_per_launch"]
+    assert abs(t - per_frame * 2048 * 200) < 1e-6 * t and 0.9 < t / (32160 * 2048 * 200) < 1.1
+    lm = b.pmc_traffic(2048, 200, 6, 25, kernel="k_lm_step")
+    assert lm is not None and lm > t                                      # the factorisation moves more bytes than the residual kernel
     assert abs(b.pmc_traffic(1024, 200, 6, 25) - t / 2) < 1e-6 * t       # scaled per frame
     assert b.pmc_traffic(2048, 200, 6, 24) is None                       # no PMC passes committed for that shape
 

@@ -572,7 +572,7 @@ def test_error_behaviour_of_the_abi(sk25, cams6, gpu_handle_factory):
         _lib.Handle(sk25, cams6, device=99)
     # sizes beyond the compiled-in maxima (cpe.h CPE_MAX_*) are refused at creation
     with pytest.raises(_lib.CpeError):
-        _lib.Handle(sk25, synth.make_cameras(9))
+        _lib.Handle(sk25, synth.make_cameras(abi.MAX_CAMS + 1))
     too_many = skeleton.build_skeleton("phantom", 25)
     too_many.n_markers = 33
     with pytest.raises(_lib.CpeError):
