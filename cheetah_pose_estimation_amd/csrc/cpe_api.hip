@@ -30,7 +30,7 @@ struct cpe_handle {
     // solver workspace
     size_t ws_frames = 0; int ws_B = 0;
     double *qbuf = nullptr, *gbuf = nullptr, *Bbuf = nullptr, *costbuf = nullptr, *Lbuf = nullptr, *zbuf = nullptr,
-           *gtbuf = nullptr, *cmax = nullptr, *mu = nullptr, *gambuf = nullptr;
+           *gtbuf = nullptr, *dgbuf = nullptr, *cmax = nullptr, *mu = nullptr, *gambuf = nullptr;
     SeqState* st = nullptr;
     int* flag = nullptr;
     int* act = nullptr;          // [ws_B] sequences of the current launch window (written by k_build_act)
@@ -447,9 +447,9 @@ static void free_kws(cpe_handle* h) {
 
 static void free_ws(cpe_handle* h) {
     free_kws(h);
-    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->cmax, h->mu, h->gambuf, h->st, h->Hlr, h->act};
+    void* ptrs[] = {h->qbuf, h->gbuf, h->Bbuf, h->costbuf, h->Lbuf, h->zbuf, h->gtbuf, h->dgbuf, h->cmax, h->mu, h->gambuf, h->st, h->Hlr, h->act};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->cmax = h->mu = h->gambuf = h->Hlr = nullptr; h->st = nullptr; h->act = nullptr;
+    h->qbuf = h->gbuf = h->Bbuf = h->costbuf = h->Lbuf = h->zbuf = h->gtbuf = h->dgbuf = h->cmax = h->mu = h->gambuf = h->Hlr = nullptr; h->st = nullptr; h->act = nullptr;
     h->ws_frames = 0; h->ws_B = 0;
 }
 
@@ -721,6 +721,7 @@ static cpe_status ensure_ws(cpe_handle* h, int B, int N) {
     HIPCHK(hipMalloc(&h->Lbuf, sizeof(double) * F * (h->pb + 1) * nu * nu));
     HIPCHK(hipMalloc(&h->zbuf, sizeof(double) * F * nu));
     HIPCHK(hipMalloc(&h->gtbuf, sizeof(double) * F * nu));
+    HIPCHK(hipMalloc(&h->dgbuf, sizeof(double) * F * nu));
     HIPCHK(hipMalloc(&h->cmax, sizeof(double) * F));
     HIPCHK(hipMalloc(&h->st, sizeof(SeqState) * B));
     HIPCHK(hipMalloc(&h->act, sizeof(int) * B));
@@ -790,9 +791,13 @@ static cpe_status lm_run(cpe_handle* h, int B, int N, const double* q_init, cons
         }
         prof_begin(h, 2);
         if (h->pb == 3) hipLaunchKernelGGL((k_lm_step<3, 0>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx);
+                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx, h->dgbuf);
         else hipLaunchKernelGGL((k_lm_step<4, 0>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx);
+                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx, h->dgbuf);
+        prof_end(h);
+        prof_begin(h, 7);
+        if (h->pb == 3) hipLaunchKernelGGL((k_lm_back<3>), dim3(slots), dim3(2 * WAVE), 0, h->stream, h->dm, h->st, prm, h->qbuf, h->Lbuf, h->zbuf, h->gtbuf, h->dgbuf, act, n_act);
+        else hipLaunchKernelGGL((k_lm_back<4>), dim3(slots), dim3(2 * WAVE), 0, h->stream, h->dm, h->st, prm, h->qbuf, h->Lbuf, h->zbuf, h->gtbuf, h->dgbuf, act, n_act);
         prof_end(h);
     };
     iterate(1, nullptr, nullptr, B);        // first evaluation and first step of every sequence
@@ -1109,7 +1114,7 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
         launch_dyn_eval(h, N, first, Fw, stance, act, n_act, slots);
         prof_begin(h, 2);
         hipLaunchKernelGGL((k_lm_step<3, 1>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, nullptr, act, n_act, 2);
+                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, nullptr, act, n_act, 2, nullptr, h->dgbuf);
         prof_end(h);
         prof_begin(h, 6);
         hipLaunchKernelGGL(k_dyn_schur, dim3(gf), dim3(KIN_THREADS), lds_kin_schur(), h->stream, h->dk, h->st, N, Fw, h->pieces, h->pmeta, h->fbuf, h->kmu, stance, h->Tbuf, act, n_act);
@@ -1117,7 +1122,8 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
         prof_end(h);
         prof_begin(h, 2);
         hipLaunchKernelGGL((k_lm_step<3, 2>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gk, h->Bk, h->costbuf,
-                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hk, act, n_act, 1);
+                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hk, act, n_act, 1, nullptr, h->dgbuf);
+        hipLaunchKernelGGL((k_lm_back<3>), dim3(slots), dim3(2 * WAVE), 0, h->stream, h->dm, h->st, prm, h->qbuf, h->Lbuf, h->zbuf, h->gtbuf, h->dgbuf, act, n_act);
         prof_end(h);
     };
     iterate(1, nullptr, nullptr, B);

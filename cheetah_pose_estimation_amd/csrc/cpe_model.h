@@ -130,6 +130,8 @@ struct SeqState {
     int32_t rejects;
     int32_t outer;      // augmented-Lagrangian multiplier updates done
     int32_t al_pending; // 1: the next k_frame_normal updates the multipliers at the current iterate
+    int32_t back_pending; // 1: k_lm_step has factored and left z; k_lm_back still has to solve and write the trial iterate
+    int32_t _pad;
     double lambda, nu, cost_cur, pred, maxstep, maxviol;
     double terms[5];    // meas, model, bound, pose, motion at the current iterate
 };

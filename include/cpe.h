@@ -165,7 +165,7 @@ cpe_status cpe_stream_wait(cpe_handle* h, void* other);     /* later launches of
 cpe_status cpe_stream_signal(cpe_handle* h, void* other);   /* `other` waits for the work the handle has queued so far */
 /* per-kernel device time of cpe_solve / cpe_solve_kinetic, accumulated by HIP events on the handle's stream while enabled
  * (what the reference stores as processing_time_s is one wall time around .solve(), acinoset_opt.py:610-618).
- * slots: 0 k_frame_normal, 1 k_lr_band, 2 k_lm_step, 3 k_build_act, 4 k_finalize, 5 k_dyn_term, 6 k_dyn_gather, 7 other */
+ * slots: 0 k_frame_normal, 1 k_lr_band, 2 k_lm_step, 3 k_build_act, 4 k_finalize, 5 k_dyn_term, 6 k_dyn_gather, 7 k_lm_back */
 #define CPE_PROFILE_SLOTS 8
 cpe_status cpe_profile_enable(cpe_handle* h, int32_t on);                              /* also clears the totals */
 cpe_status cpe_profile_get(cpe_handle* h, double* ms /*[8]*/, int64_t* launches /*[8]*/);

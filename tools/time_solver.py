@@ -25,16 +25,19 @@ T = {k: torch.tensor(d[k], device=dev).repeat((rep,) + (1,) * (d[k].ndim - 1))[:
 q = torch.empty_like(T["q_init"]); dq = torch.empty_like(q); ddq = torch.empty_like(q)
 pos = torch.empty((args.B, args.N, 25, 3), dtype=torch.float64, device=dev); me = torch.empty((args.B, args.N, 6, 25, 2), dtype=torch.float64, device=dev)
 for rnd in range(3):
+    if rnd == 2:
+        h.profile(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st, stats = h.solve(T["q_init"], T["meas"], T["weight"], q, dq, ddq, pos, me)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
 its = np.mean([s.iterations for s in stats])
+print("   per-kernel ms/launch:", ", ".join(f"{k} {ms / n:.3f} x{n}" for k, (ms, n) in h.profile_totals().items()))
 if hasattr(h.lib, "cpe_debug_lm_stamps"):
     import ctypes as C
     z = (C.c_ulonglong * 16)()
     h.lib.cpe_debug_lm_stamps(z)
     tot = sum(z) or 1
-    names = ["accept/reduce", "init rows", "chol", "trsm", "update+Lwrite", "store_row", "bwd partial", "bwd subst+storeL", "dot products", "q update", "row dense", "row motion", "bwd subst (thread 0 view)", "bwd wait for L prefetch + LDS store", "s14", "s15"]
+    names = ["accept/reduce", "init rows", "chol", "trsm", "update+Lwrite", "store_row", "back: partial sums", "back: substitution", "end of k_lm_step", "loader: issue", "row dense", "row motion", "back: stores", "back: barrier", "loader: vmcnt wait", "loader: barrier"]
     print("k_lm_step phase shares (block 0, last solve):", ", ".join(f"{n} {100.0 * z[i] / tot:.1f}%" for i, n in enumerate(names)), f" total cycles/launch {tot / max(its + 1, 1):.3g}")
 if hasattr(h.lib, "cpe_debug_fn_stamps"):
     import ctypes as C
