@@ -1248,9 +1248,9 @@ cpe_status cpe_debug_fn_stamps(unsigned long long* out16) {
     return CPE_OK;
 }
 // diagnostic build only: per-phase shader-clock totals accumulated by block 0 of k_lm_step since the last call
-cpe_status cpe_debug_lm_stamps(unsigned long long* out16) {
-    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16));
-    unsigned long long z[16] = {0};
+cpe_status cpe_debug_lm_stamps(unsigned long long* out32) {
+    HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 32));
+    unsigned long long z[32] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lm_stamps), z, sizeof(z)));
     return CPE_OK;
 }

@@ -525,10 +525,12 @@ def test_solve_short_sequences(N, b, sk25, cams6, oracle, gpu_handle_factory):
     # whatever path was taken, the reported cost is the oracle's objective at the returned trajectory
     terms = oracle.objective(sk25, cams6, opts, None, out["q"][b], d["meas"][b], d["weight"][b])[3]
     assert abs(st.cost - opts.cost_scale * (terms[0] + terms[1])) < 1e-9 * abs(st.cost)     # measurement + model (the bound term is not part of obj_cost)
-    assert st.status == rs.status
     if (N, b) in _SHORT_CREEP:
-        assert st.status == abi.MAX_ITER                                   # both implementations creep to the limit
-        pytest.xfail("flat directions without the motion coupling: both implementations stop at the iteration limit, apart")
+        # at least one implementation creeps to the limit (round 2, matrix-core factorisation: HIP gets out of the flat region of
+        # case (3, 0) and converges, the oracle still does not); no parity statement is made here
+        assert abi.MAX_ITER in (st.status, rs.status)
+        pytest.xfail("flat directions without the motion coupling: the implementations stop apart, at the iteration limit or after different paths")
+    assert st.status == rs.status
     assert st.status == abi.OK
     assert abs(st.iterations - rs.iterations) <= 2
     assert abs(st.cost - rs.cost) < 1e-6 * abs(rs.cost)

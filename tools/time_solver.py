@@ -34,11 +34,18 @@ its = np.mean([s.iterations for s in stats])
 print("   per-kernel ms/launch:", ", ".join(f"{k} {ms / n:.3f} x{n}" for k, (ms, n) in h.profile_totals().items()))
 if hasattr(h.lib, "cpe_debug_lm_stamps"):
     import ctypes as C
-    z = (C.c_ulonglong * 16)()
+    z = (C.c_ulonglong * 32)()
     h.lib.cpe_debug_lm_stamps(z)
-    tot = sum(z) or 1
-    names = ["accept/reduce", "init rows", "chol", "trsm", "update+Lwrite", "store_row", "back: partial sums", "back: substitution", "end of k_lm_step", "loader: issue", "row dense", "row motion", "back: stores", "back: barrier", "loader: vmcnt wait", "loader: barrier"]
-    print("k_lm_step phase shares (block 0, last solve):", ", ".join(f"{n} {100.0 * z[i] / tot:.1f}%" for i, n in enumerate(names)), f" total cycles/launch {tot / max(its + 1, 1):.3g}")
+    # three timelines of workgroup 0: the factor wave (thread 0), an update wave (thread 64), and k_lm_back's two waves
+    groups = {"k_lm_step factor wave": {0: "accept/reduce", 1: "stage rows", 2: "sweep", 3: "wait for A11"},
+              "k_lm_step update wave": {10: "wait for sweep", 4: "P1 panel product", 9: "sync", 5: "P2 trailing update", 6: "vmcnt(0)", 7: "sync",
+                                        12: "wait staged", 14: "R singles", 15: "R heavy", 11: "R gradient", 13: "sync"},
+              "k_lm_back arithmetic wave": {22: "partial sums", 23: "substitution", 28: "stores", 29: "barrier"},
+              "k_lm_back loader wave": {25: "issue", 30: "vmcnt wait", 31: "barrier"}}
+    for gname, items in groups.items():
+        tot = sum(z[i] for i in items) or 1
+        print(f"{gname}: " + ", ".join(f"{n} {100.0 * z[i] / tot:.1f}%" for i, n in items.items()) + f"  [{tot / max(its + 1, 1):.3g} cycles/launch]")
+    print(f"factorisation failures (all workgroups): {z[8]}")
 if hasattr(h.lib, "cpe_debug_fn_stamps"):
     import ctypes as C
     z = (C.c_ulonglong * 16)()
