@@ -41,12 +41,12 @@ def resjac_bytes_per_frame(C, L, S, nq, with_cost):
 def solve_bytes_per_frame_iteration(C, L, nq=54, nu=28, nrev=12, pb=3):
     """ALGORITHMIC bytes one LM iteration moves per frame: k_frame_normal reads the state (nq + nrev), meas, weight and
     writes B (nu^2), g, Gamma (4 nrev), the cost record (8) and the consistent Euler angles; k_lm_step reads B, g, Gamma, the state
-    and the cost record, writes the factor column ((pb+1) nu^2), z and the total gradient, reads the factor column and z back in the
-    backward pass, writes delta, reads gradient + delta + diag(B) for the predicted reduction, and reads + writes the state for the
-    trial iterate."""
+    and the cost record, writes the factor column ((pb+1) nu^2), z, the total gradient and the undamped diagonal; k_lm_back reads the
+    factor column and z back, writes delta, reads gradient + diagonal for the predicted reduction, and reads + writes the state for
+    the trial iterate.  (lm = the two kernels of the step together.)"""
     ns = nq + nrev
     fn = 8 * (ns + 2 * C * L + C * L + nu * nu + nu + 4 * nrev + 8 + nq)
-    lm = 8 * (nu * nu + nu + 4 * nrev + ns + 8 + (pb + 1) * nu * nu + 2 * nu + (pb + 1) * nu * nu + nu + nu + 3 * nu + 2 * ns)
+    lm = 8 * (nu * nu + nu + 4 * nrev + ns + 8 + (pb + 1) * nu * nu + 3 * nu + (pb + 1) * nu * nu + nu + nu + 2 * nu + 2 * ns)
     return fn, lm
 
 
@@ -353,13 +353,18 @@ def main():
         frame_its = float((its + 1).sum()) * N
         fn_b, lm_b = solve_bytes_per_frame_iteration(C, L, sk.nq, h.nu, 12, 3)
         lm_ms, lm_n = prof.get("k_lm_step", (0.0, 0))
+        bk_ms, _ = prof.get("k_lm_back", (0.0, 0))
+        fwd_ms = lm_ms
+        lm_ms += bk_ms                                    # the step is two kernels since round 2: factor (k_lm_step) + solve (k_lm_back)
         fn_ms, fn_n = prof.get("k_frame_normal", (0.0, 0))
         wframe_its = float((np.array([s.iterations for s in wstats]) + 1).sum()) * N
-        roof = {"bound": "hbm", "kernel": "k_lm_step<3>", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+        roof = {"bound": "hbm", "kernel": "k_lm_step<3> + k_lm_back<3>", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
                 "achieved": (lm_b * wframe_its / (lm_ms * 1e-3) / 1e9) if lm_ms else None,
                 "frac": (lm_b * wframe_its / (lm_ms * 1e-3) / HBM_PEAK) if lm_ms else None,
                 "traffic": pmc_traffic(min(Bs, 512), N, C, L, "k_lm_step"),          # per full launch window (512 sequences)
                 "bytes_per_frame_iteration": lm_b, "kernel_ms_total": lm_ms, "launches": lm_n,
+                "ms_per_launch": {"k_lm_step": fwd_ms / lm_n if lm_n else None, "k_lm_back": bk_ms / lm_n if lm_n else None,
+                                  "k_frame_normal": fn_ms / fn_n if fn_n else None},
                 "fp64": {"achieved_tflops": (lm_flops_per_frame_iteration() * wframe_its / (lm_ms * 1e-3) / 1e12) if lm_ms else None,
                          "peak_tflops": FP64_PEAK / 1e12,
                          "frac": (lm_flops_per_frame_iteration() * wframe_its / (lm_ms * 1e-3) / FP64_PEAK) if lm_ms else None},
@@ -367,7 +372,7 @@ def main():
                                    "frac": (fn_b * wframe_its / (fn_ms * 1e-3) / HBM_PEAK) if fn_ms else None},
                 "whole_solve": {"bytes_per_frame_iteration": fn_b + lm_b, "achieved": (fn_b + lm_b) * frame_its / el / 1e9,
                                 "frac": (fn_b + lm_b) * frame_its / el / HBM_PEAK},
-                "note": "latency-bound (200 sequential block columns x 28 pivots per sequence): far from both rooflines, see DESIGN.md 6"}
+                "note": "latency-bound (200 sequential block columns x 28 pivots per sequence, two 80 KB workgroups per CU): far from both rooflines, see DESIGN.md 6"}
         solves = dict(value=world * Bs / el, unit="solves/s", batch_per_gpu=Bs, seconds=el, iterations_mean=float(its.mean()),
                       iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()), roofline=roof)
         if world == 1:
