@@ -37,8 +37,8 @@ if hasattr(h.lib, "cpe_debug_lm_stamps"):
     z = (C.c_ulonglong * 32)()
     h.lib.cpe_debug_lm_stamps(z)
     # three timelines of workgroup 0: the factor wave (thread 0), an update wave (thread 64), and k_lm_back's two waves
-    groups = {"k_lm_step factor wave": {0: "accept/reduce", 1: "stage rows", 2: "sweep", 3: "wait for A11"},
-              "k_lm_step update wave": {10: "wait for sweep", 4: "P1 panel product", 9: "sync", 5: "P2 trailing update", 6: "vmcnt(0)", 7: "sync",
+    groups = {"k_lm_step factor wave": {0: "accept/reduce", 1: "stage rows", 2: "sweep", 3: "wait for P1", 6: "A11 tiles + rhs"},
+              "k_lm_step update wave": {10: "wait for sweep", 4: "P1 panel product", 9: "sync", 5: "P2 trailing update", 7: "sync",
                                         12: "wait staged", 14: "R singles", 15: "R heavy", 11: "R gradient", 13: "sync"},
               "k_lm_back arithmetic wave": {22: "partial sums", 23: "substitution", 28: "stores", 29: "barrier"},
               "k_lm_back loader wave": {25: "issue", 30: "vmcnt wait", 31: "barrier"}}
