@@ -128,6 +128,8 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
         if (s->rel_ref[p] >= 0 && m.rel_ref_u[k] < 0) return fail(CPE_BAD_ARG, "relative angle references a dependent dof");
     }
     // joint bodies and S column layout
+    m.n_srow = 0;
+    for (int r = 0; r < CPE_MAX_DEP; r++) m.srow[r] = -1;
     for (int j = 0; j < s->n_joints; j++) {
         const int p = m.joint_parent[j], c = m.joint_child[j], r = m.joint_dep0[j];
         if (m.joint_kind[j] == CPE_JOINT_REVOLUTE_Y) {
@@ -148,6 +150,7 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             }
         } else {
             m.joint_body[j] = p;
+            m.srow[r] = m.n_srow++;
             int n = 0;
             auto add = [&](int col, int kind, int ang, int chain) -> bool {
                 for (int e = 0; e < n; e++)
@@ -168,7 +171,7 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
                     if (m.dep_level[pr] != 0 || m.joint_kind[m.dep_joint[pr]] != CPE_JOINT_HOOKE_YZ)
                         return fail(CPE_BAD_ARG, "hooke chains deeper than two are not supported");
                     m.dep_level[r] = 1;
-                    for (int e = 0; e < m.scol_n[pr] && ok; e++) ok = add(m.scol[pr][e], 2, 0, pr * CPE_MAX_SCOL + e);
+                    for (int e = 0; e < m.scol_n[pr] && ok; e++) ok = add(m.scol[pr][e], 2, 0, m.srow[pr] * CPE_MAX_SCOL + e);
                 }
             }
             if (!ok) return fail(CPE_BAD_ARG, "too many columns in a hooke row");
@@ -253,7 +256,7 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
                 const int p = 3 + 3 * link + a;
                 if (sl < 0) { ok = false; break; }
                 if (m.u_of_q[p] >= 0) ok = add_term(m.u_of_q[p], sl, -1);
-                else { const int r = m.dep_of_q[p]; for (int e = 0; e < m.scol_n[r] && ok; e++) ok = add_term(m.scol[r][e], sl, r * CPE_MAX_SCOL + e); }
+                else { const int r = m.dep_of_q[p]; for (int e = 0; e < m.scol_n[r] && ok; e++) ok = m.srow[r] >= 0 && add_term(m.scol[r][e], sl, m.srow[r] * CPE_MAX_SCOL + e); }
             }
         }
         if (n_trunk_chain < n && ok) {
@@ -299,6 +302,20 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
     }
     m.S = S; m.mcol_off[L] = mct; m.mc_total = mct;
     if (S > 5 * WAVE) return fail(CPE_BAD_ARG, "more than 320 Jacobian slots");
+    {   // flat term list of the reduced marker columns (see cpe_model.h)
+        m.tl_n = 0;
+        for (int l = 0; l < L; l++)
+            for (int e = 0; e < m.mcol_n[l]; e++)
+                for (int k = 0; k < m.term_n[l][e]; k++) {
+                    if (m.tl_n >= CPE_MAX_TL) return fail(CPE_BAD_ARG, "too many marker-column terms");
+                    const int sl = m.term_slot[l][e][k], si = m.term_s[l][e][k], item = m.mcol_off[l] + e;
+                    if (item >= 1024 || si + 1 >= 1024 || m.ss_vdyn[sl] + 1 >= 1024) return fail(CPE_BAD_ARG, "marker-column term out of range");
+                    auto& T = m.tl[m.tl_n++];
+                    T.w0 = item | ((si + 1) << 10) | ((m.ss_vdyn[sl] + 1) << 20);
+                    T.moff = m.ss_moff[sl];
+                    for (int d = 0; d < 3; d++) T.v[d] = m.ss_vec[sl][d];
+                }
+    }
     {   // gather lists for H and g (see cpe_model.h)
         const int nu_ = m.nu;
         std::vector<std::vector<uint32_t>> by_entry(nu_ * nu_);
@@ -311,6 +328,8 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
                 }
         std::vector<int> order;
         for (int e = 0; e < nu_ * nu_; e++) if (!by_entry[e].empty()) order.push_back(e);
+        for (auto& w : m.h_covered) w = 0;
+        for (int e : order) { const int a = e / nu_, b = e % nu_; for (int t : {a * nu_ + b, b * nu_ + a}) m.h_covered[t >> 5] |= 1u << (t & 31); }
         std::sort(order.begin(), order.end(), [&](int x, int y) { return by_entry[x].size() != by_entry[y].size() ? by_entry[x].size() > by_entry[y].size() : x < y; });
         int load[64] = {0};
         for (int e : order) {
@@ -341,10 +360,13 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
     return CPE_OK;
 }
 
+// the plain variant of k_frame_normal (no Gaussian-mixture prior, no shutter delay) writes H straight to HBM and needs 6 KB less LDS per wave
+#define FRAME_NORMAL(plain) ((plain) ? k_frame_normal<true> : k_frame_normal<false>)
 static size_t lds_fk(const DevModel& m) { return sizeof(double) * (m.nq + 6 * m.nl + 36 * m.nl + 3 * m.L + 23 * m.C); }
 static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0, bool shutter = false) {
-    // H | g overlay the solver-slot vectors dp and the S rows (dead once Dp is built): the larger of the two
-    size_t ov = 3 * m.ss_n + CPE_MAX_SCOL * m.ndep, hg = m.nu * m.nu + m.nu;
+    // g (and, unless the plain variant writes H straight to HBM, H | g) overlay the S rows, which are dead once Dp is built
+    const bool plain = gmm_k == 0 && !shutter;
+    size_t ov = CPE_MAX_SCOL * m.n_srow, hg = plain ? m.nu : m.nu * m.nu + m.nu;
     size_t n = m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.n_trunk + 3 * m.L + 3 * m.sv_n + GAM_STRIDE * m.nrev + (ov > hg ? ov : hg) +
                9 * m.L + 3 * m.mc_total;
     if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX + gmm_dim * gmm_dim + 2 * gmm_dim * m.nu;
@@ -744,8 +766,8 @@ cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q,
     hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q, h->qbuf);
     HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
-    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
-                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr);
+    hipLaunchKernelGGL(FRAME_NORMAL(h->gmm_k == 0), dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr, ShutterArgs{nullptr, nullptr, nullptr});
     HIPCHK(hipMemcpyAsync(g, h->gbuf, sizeof(double) * F * m.nu, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(Bm, h->Bbuf, sizeof(double) * F * m.nu * m.nu, hipMemcpyDeviceToDevice, h->stream));
     hipLaunchKernelGGL(k_gather_normal, dim3((unsigned)F), dim3(128), 0, h->stream, h->dm, F, h->qbuf, h->costbuf, h->gambuf, cost, gam, q_out);
@@ -780,7 +802,7 @@ static cpe_status lm_run(cpe_handle* h, int B, int N, const double* q_init, cons
     auto iterate = [&](int first, const int* act, const int* n_act, int slots) {
         const unsigned gf = (unsigned)((size_t)slots * N);
         prof_begin(h, 0);
-        hipLaunchKernelGGL(k_frame_normal, dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
+        hipLaunchKernelGGL(FRAME_NORMAL(h->gmm_k == 0 && sh.tau == nullptr), dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
                            h->costbuf, h->mu, h->gambuf, h->pri, act, n_act, sh);
         prof_end(h);
         if (lr) {
@@ -1108,8 +1130,8 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
     auto iterate = [&](int first, const int* act, const int* n_act, int slots) {
         const unsigned gf = (unsigned)((size_t)slots * N);
         prof_begin(h, 0);
-        hipLaunchKernelGGL(k_frame_normal, dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
-                           h->costbuf, h->mu, h->gambuf, h->pri, act, n_act);
+        hipLaunchKernelGGL(FRAME_NORMAL(h->gmm_k == 0), dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
+                           h->costbuf, h->mu, h->gambuf, h->pri, act, n_act, ShutterArgs{nullptr, nullptr, nullptr});
         prof_end(h);
         launch_dyn_eval(h, N, first, Fw, stance, act, n_act, slots);
         prof_begin(h, 2);
@@ -1215,8 +1237,8 @@ cpe_status cpe_eval_kinetic_nodes(cpe_handle* h, const cpe_kinetic_options* opt,
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     HIPCHK(hipMemsetAsync(h->fbuf, 0, sizeof(double) * 2 * F * KIN_LS, h->stream));
     HIPCHK(hipMemsetAsync(h->kmu, 0, sizeof(double) * F * 4 * KIN_MU, h->stream));
-    hipLaunchKernelGGL(k_frame_normal, dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
-                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr);
+    hipLaunchKernelGGL(FRAME_NORMAL(h->gmm_k == 0), dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
+                       h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr, ShutterArgs{nullptr, nullptr, nullptr});
     launch_dyn_eval(h, N, 1, F, stance, nullptr, nullptr, B);
     HIPCHK(hipGetLastError());
     if (f) HIPCHK(hipMemcpyAsync(f, h->fbuf, sizeof(double) * F * KIN_LS, hipMemcpyDeviceToDevice, h->stream));

@@ -6,6 +6,7 @@
 #include "../../include/cpe.h"
 
 #define CPE_MAX_CHAIN 6     // links on the path root -> marker link (paw: base,bodyF,thigh,calf,hock)
+#define CPE_MAX_TL 512      // terms of all reduced marker columns (cheetah: ~300)
 #define CPE_MAX_SLOTS 320   // structurally non-zero (marker,dof) pairs; 276 for the 25-marker cheetah
 #define CPE_MAX_MCOL 12     // reduced (independent) dofs a marker depends on
 #define CPE_MAX_TERMS 8     // terms of one reduced marker-Jacobian column (1 direct + dependent angles)
@@ -59,7 +60,7 @@ struct DevModel {
     int32_t scol[CPE_MAX_DEP][CPE_MAX_SCOL];
 
     // reduced marker Jacobian Dp_l[:, j] (j < mcol_n[l], reduced column mcol[l][j]) =
-    //   sum_{t < term_n} dp[term_slot] * (term_s < 0 ? 1 : Sval[term_s])     (Sval flat index = r*CPE_MAX_SCOL + j)
+    //   sum_{t < term_n} dp[term_slot] * (term_s < 0 ? 1 : Sval[term_s])     (Sval flat index = srow[r]*CPE_MAX_SCOL + j)
     int32_t mcol_n[CPE_MAX_MARKERS];
     int32_t mcol[CPE_MAX_MARKERS][CPE_MAX_MCOL];
     int32_t mcol_off[CPE_MAX_MARKERS + 1];                 // prefix sum of mcol_n
@@ -76,6 +77,11 @@ struct DevModel {
     uint32_t hg_code[CPE_MAX_HG][64];
     int32_t gg_cnt[CPE_NX];
     uint16_t gg_code[CPE_MAX_GG][CPE_NX];             // ci | marker << 8
+    // flat list of the terms of all reduced marker columns (k_frame_normal builds Dp from it, one term per lane per round, no staging of the
+    // slot vectors): item = (marker, column) index into Dp; w0 = item | (S index + 1) << 10 | (dynamic vector + 1) << 20; moff / vec as ss_*
+    int32_t tl_n;
+    struct alignas(16) { int32_t w0, moff; double v[3]; } tl[CPE_MAX_TL];
+    uint32_t h_covered[(CPE_NX * CPE_NX + 31) / 32];   // entries of H (row-major) that the gather list writes; the others are structural zeros
     int16_t mc_marker[CPE_MAX_MARKERS * CPE_MAX_MCOL];
     int16_t mc_j[CPE_MAX_MARKERS * CPE_MAX_MCOL];
 
@@ -87,6 +93,7 @@ struct DevModel {
     int16_t hk_chain[CPE_MAX_DEP][CPE_MAX_SCOL];
     int32_t dep_joint[CPE_MAX_DEP];      // joint that defines dependent row r
     int32_t dep_level[CPE_MAX_DEP];      // 0: parent fully independent (or revolute); 1: parent's phi dependent
+    int32_t srow[CPE_MAX_DEP], n_srow;   // hooke rows only get S values computed: compact row index (Sval flat index = srow * CPE_MAX_SCOL + j), -1 otherwise
 
     // ---- solver parametrisation: leg link c = body B rotated about B's y axis by alpha_c.
     // State of one frame: ns = nq + nrev doubles = Euler q followed by the leg angles alpha.
