@@ -155,7 +155,7 @@ def pmc_traffic(B, N, C, L, kernel="k_resjac"):
     None if no profile for this marker / camera count (or kernel) is committed."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc*.json"))):
         try:
             with open(f) as fh:
                 j = json.load(fh)

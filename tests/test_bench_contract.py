@@ -35,7 +35,8 @@ def test_algorithmic_bytes_and_traffic_record():
     per_frame = rec["kernels"]["k_resjac<false"]["total_corrected"] / rec["frames_per_launch"]
     assert abs(t - per_frame * 2048 * 200) < 1e-6 * t and 0.9 < t / (32160 * 2048 * 200) < 1.1
     lm = b.pmc_traffic(2048, 200, 6, 25, kernel="k_lm_step")
-    assert lm is not None and lm > t                                      # the factorisation moves more bytes than the residual kernel
+    bk = b.pmc_traffic(2048, 200, 6, 25, kernel="k_lm_back")
+    assert lm is not None and bk is not None and lm + bk > t              # factor + solve kernels together move more bytes than the residual kernel
     assert abs(b.pmc_traffic(1024, 200, 6, 25) - t / 2) < 1e-6 * t       # scaled per frame
     assert b.pmc_traffic(2048, 200, 6, 24) is None                       # no PMC passes committed for that shape
 
