@@ -1024,7 +1024,7 @@ void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kin
     o->inner_iterations = 30; o->_pad = 0;
 }
 
-static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt) {
+static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const double* grf_fix = nullptr) {
     const DevModel& m = h->hm;
     DevKin& K = h->hk;
     memset(&K, 0, sizeof(K));
@@ -1050,6 +1050,7 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt) {
     double mt = 0; for (int i = 0; i < m.nl; i++) mt += m.mass[i];
     K.Mg = mt * d.eom.gravity; K.h = h->opts.h; K.ih = 1.0 / h->opts.h;
     for (int i = 0; i < m.nl; i++) { uint32_t mask = 0; for (int j = 0; j < m.nl; j++) { int a = j; while (a >= 0 && a != i) a = m.parent[a]; if (a == i) mask |= 1u << j; } K.sub_mask[i] = mask; }
+    K.grf_fix = grf_fix;
     if (!h->dk) HIPCHK(hipMalloc(&h->dk, sizeof(DevKin)));
     HIPCHK(hipMemcpyAsync(h->dk, &K, sizeof(DevKin), hipMemcpyHostToDevice, h->stream));
     return CPE_OK;
@@ -1100,6 +1101,13 @@ static void launch_dyn_eval(cpe_handle* h, int N, int first, size_t Fw, const in
 cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
                              const double* weight, const int32_t* stance, double* q, double* dq, double* ddq, double* positions,
                              double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats, cpe_kinetic_stats* kstats) {
+    return cpe_solve_kinetic_fixed(h, opt, B, N, q_init, meas, weight, stance, nullptr, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
+}
+
+cpe_status cpe_solve_kinetic_fixed(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                   const double* weight, const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq,
+                                   double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                   cpe_kinetic_stats* kstats) {
     if (!h || !opt || !q_init || !meas || !weight || !stance || !q) return fail(CPE_BAD_ARG, "null argument");
     if ((dq == nullptr) != (ddq == nullptr)) return fail(CPE_BAD_ARG, "dq and ddq must be given together");
     if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
@@ -1108,7 +1116,7 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
     if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
     if (h->pb != 3) return fail(CPE_BAD_ARG, "the physics-based model runs on the half-bandwidth-3 solver");
     HIPCHK(hipSetDevice(h->device));
-    cpe_status s = build_kin(h, opt);
+    cpe_status s = build_kin(h, opt, grf_fixed);
     if (s != CPE_OK) return s;
     s = ensure_ws(h, B, N);
     if (s != CPE_OK) return s;

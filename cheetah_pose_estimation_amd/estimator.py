@@ -277,6 +277,7 @@ class CheetahEstimator:
     device: int = 0
     opt_time_s: float = 0.0
     shutter_delay: Optional[np.ndarray] = None   # [C] seconds, set by estimate_kinematics when enable_shutter_delay_estimation
+    synthesised_grf: Optional[dict] = None       # {foot: GRFz per frame}: the profile estimate_kinetics(joint_estimation=False) prescribed (acinoset_opt.py:823)
     costs: Dict[str, float] = field(default_factory=dict)
     result: Optional[dict] = None
     com_pos: Optional[np.ndarray] = None
@@ -608,6 +609,40 @@ def stance_from_contacts(contact_json: dict, n_frames: int, first_frame: int) ->
     return st
 
 
+def load_force_table(path_csv: str) -> Dict[int, np.ndarray]:
+    """`grf/data_synth.csv` (or a `grf/data.csv` twin of the measured force plates): {force plate: array [rows, 3] = (Fx, Fy, Fz)} in file order --
+    the table the reference reads with `pd.read_hdf(...).query("force_plate == k")` (acinoset_misc.py:960, :981)"""
+    rows = np.genfromtxt(path_csv, delimiter=",", skip_header=1)
+    rows = rows.reshape(-1, 5)
+    return {int(k): rows[rows[:, 0] == k][:, 2:5] for k in np.unique(rows[:, 0])}
+
+
+def grf_profile(plates: Dict[int, np.ndarray], contact_json: dict, n_frames: int) -> Tuple[np.ndarray, np.ndarray]:
+    """`misc.get_grf_profile` for tables that are already per frame (its `synthetic_data` path, acinoset_misc.py:946-1026): grfz [N, 4] and
+    grfxy [N, 4, 4] (friction-polygon sides +x, +y, -x, -y) in skeleton.FEET order.  As there: only the FIRST contact of a foot (it "assumes a
+    single stride"), frames 0 .. N-2 (`for fe in range(1, nfe)`), the table row is the frame's offset from the contact file's start frame, and of
+    the horizontal force only the LARGEST positive polygon component is kept."""
+    start = contact_json["start_frame"]
+    gz = np.zeros((n_frames, len(skeleton.FEET))); gxy = np.zeros((n_frames, len(skeleton.FEET), 4))
+    for k, foot in enumerate(skeleton.FEET):
+        rec = contact_json["contacts"].get(f"{foot}_foot")
+        if not rec:
+            continue
+        first, last, plate = int(rec[0][0]), int(rec[0][1]), int(rec[0][2]) - 1
+        F = plates.get(plate)
+        if F is None:
+            continue
+        for n in range(n_frames - 1):
+            if first <= start + n <= last and n < len(F):
+                fx, fy, fz = F[n]
+                gz[n, k] = fz
+                comps = np.array([fx, fy, -fx, -fy])
+                i = int(np.argmax(comps))
+                if comps[i] > 0:
+                    gxy[n, k, i] = comps[i]
+    return gz, gxy
+
+
 def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, auto: bool = True, use_2d_reprojections: bool = True,
                       solver_output: bool = True, init_prev_kinematic_solution: bool = True, synthesised_grf: bool = False,
                       no_slip: bool = True, joint_estimation: bool = False, fix_grf: bool = True, ground_constraint: bool = False,
@@ -617,15 +652,18 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     """Same signature and meaning as acinoset_opt.estimate_kinetics (acinoset_opt.py:693-708) for the branch its drivers run for the
     physics-based reconstruction (`joint_estimation=True`, run_dataset.py:1198-1229): torques, joint constraint forces, ground-reaction
     forces and the trajectory are estimated together, warm-started from the kinematic solution on disk, with the contact windows of
-    `grf/autogen-contact.json` (auto) or `metadata.json`.  The whole NLP runs on the GPU (cpe_solve_kinetic).  `init_torques` has no
-    effect here: the torques are minimised out exactly at every evaluation, so they need no starting value.  Branches that prescribe
-    the forces from a file (`joint_estimation=False`: synthesised or per-frame-fitted GRF held fixed) are not built."""
+    `grf/autogen-contact.json` (auto) or `metadata.json`; and for the branch of the kinetic-dataset driver (`joint_estimation=False`,
+    `fix_grf=True`, run_dataset.py:1092-1140; acinoset_opt.py:813-866): the ground-reaction forces are PRESCRIBED -- the synthesised profile of
+    `grf/data_synth.csv` (`synthesised_grf=True`) or the per-frame fit of `CheetahEstimator.estimate_grf` -- the feet are held near the ground
+    (`ground_constraint`) and still (`no_slip`) while their force is positive, and torques, constraint forces and the trajectory are estimated
+    (cpe_solve_kinetic_fixed).  The whole NLP runs on the GPU.  `init_torques` has no effect here: the torques are minimised out exactly at
+    every evaluation, so they need no starting value.  `fix_grf=False` (forces free within 20 % of the profile) is not built."""
     est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
     if est.kinematic_model:
         raise AssertionError("Dynamic model of the cheetah is required.")          # the reference asserts hasattr(model, 'eom_f')
-    if not joint_estimation:
-        raise NotImplementedError("estimate_kinetics with prescribed ground-reaction forces (joint_estimation=False) is not built; "
-                                  "the physics-based reconstruction of run_dataset.py uses joint_estimation=True")
+    if not joint_estimation and not fix_grf:
+        raise NotImplementedError("estimate_kinetics(joint_estimation=False, fix_grf=False): forces boxed to +-20 % of a profile are not built "
+                                  "(the node forces would need a box-constrained elimination)")
     if not use_2d_reprojections:
         raise NotImplementedError("the 3D kinematic cost (use_2d_reprojections=False) is not built")
     if params.enable_shutter_delay_estimation and scene.cam_idx is None:
@@ -646,7 +684,25 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
             q_init[:, 3 + 3 * i + 2] = psi[sl]
     with open(os.path.join(data_dir, "grf", "autogen-contact.json") if auto else os.path.join(params.data_dir, "metadata.json"), "r", encoding="utf-8") as fh:
         contact_json = json.load(fh)
-    stance = stance_from_contacts(contact_json, N, params.start_frame)
+    grf_fixed = None
+    if joint_estimation:
+        stance = stance_from_contacts(contact_json, N, params.start_frame)
+    else:
+        if synthesised_grf:                                                          # acinoset_opt.py:814-820
+            table = os.path.join(data_dir if auto else params.data_dir, "grf", "data_synth.csv" if auto else "data.csv")
+            if not os.path.exists(table):
+                raise FileNotFoundError(f"{table}: the force table of the prescribed-force branch (determine_contacts writes grf/data_synth.csv; the measured "
+                                        "force plates ship as grf/data.h5 in the reference, which needs PyTables -- provide a CSV twin)")
+            gz, gxy = grf_profile(load_force_table(table), contact_json, N)
+        else:                                                                        # :821-822: the per-frame fit
+            gzd, gxyd = est.estimate_grf(monocular=True, plot=False, out_dir_prefix=out_dir_prefix)
+            gz = np.zeros((N, 4)); gxy = np.zeros((N, 4, 4))
+            for k, foot in enumerate(skeleton.FEET):
+                v = np.asarray(gzd[f"{foot}_foot"], dtype=np.float64); w = np.asarray(gxyd[f"{foot}_foot"], dtype=np.float64).reshape(-1, 4)
+                gz[:min(N, len(v)), k] = v[:N]; gxy[:min(N, len(w)), k] = w[:N]
+        est.synthesised_grf = {f"{foot}_foot": [float(v) for v in gz[:, k]] for k, foot in enumerate(skeleton.FEET)}
+        stance = (gz > 0).astype(np.int32)                                           # height / no-slip rules where a force acts (:832-835, :853-864)
+        grf_fixed = np.ascontiguousarray(np.stack([gz, gxy[..., 0] - gxy[..., 2], gxy[..., 1] - gxy[..., 3]], axis=-1))
     pri = None
     if not disable_pose_prior and scene.cam_idx is not None:                         # acinoset_opt.py:916-917
         from . import priors as _priors
@@ -658,6 +714,8 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     ko = kinetic_options if kinetic_options is not None else abi.default_kinetic_options(skeleton.dyn_options(est.name), scene.fps, params.kinetic_dataset)
     if not no_slip:
         ko.slip_max = 0.0
+    if not joint_estimation and not ground_constraint:
+        ko.foot_height_tol = 1e9                                                     # the feet are not tied to the ground (:832)
     if disable_motion_prior:
         ko.w_torque, ko.w_smooth = 0.0, 0.0                                          # acinoset_opt.py:918-920
     if est.bound_eom_error is not None:
@@ -666,7 +724,8 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     h = _lib.Handle(skk, est.cams, opts, pri, device=est.device)
     try:
         t0 = time()
-        res = h.solve_kinetic_host(ko, q_init[None], est.meas[None], est.weight[None], stance[None])
+        res = h.solve_kinetic_host(ko, q_init[None], est.meas[None], est.weight[None], stance[None],
+                                   grf_fixed=None if grf_fixed is None else grf_fixed[None])
         est.opt_time_s = time() - t0
         import torch
         dev = torch.device("cuda", est.device)

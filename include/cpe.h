@@ -374,6 +374,16 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
                              double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                              cpe_kinetic_stats* kstats);
 
+/* the same with PRESCRIBED foot forces (estimate_kinetics(joint_estimation=False, fix_grf=True), acinoset_opt.py:813-838: GRFz / GRFxy fixed to a
+ * synthesised or previously fitted profile): grf_fixed [B][N][n_feet][3] = net force (z, x, y) of every foot in body weights, device pointer,
+ * read where stance != 0 (elsewhere the force is zero as before).  The foot forces stop being unknowns of the node -- only torques and
+ * joint constraint forces are eliminated -- and the friction / positivity rows drop out, as the reference removes its friction constraint for fixed
+ * forces; the foot-height and no-slip rules of the stance frames stay.  grf_fixed == NULL is cpe_solve_kinetic. */
+cpe_status cpe_solve_kinetic_fixed(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                   const double* weight, const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq,
+                                   double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                   cpe_kinetic_stats* kstats);
+
 /* diagnostic building block of cpe_solve_kinetic (as cpe_eval_normal is of cpe_solve): ONE evaluation of the physics terms of every node at
  * Euler q, multipliers zero, forces from a cold start -- what ASL hands IPOPT per node for the constraints of make_pyomo_model(include_eom_slack=True)
  * (acinoset_opt.py:510-514) after the node forces are minimised out.  Device pointers, each may be NULL: f [B][N][64] node forces (tau | lambda |

@@ -1185,14 +1185,25 @@ void cpo_kinetic_nodes(const cpe_skeleton* s, const cpe_camera* cams, int C, con
 }
 
 /* physics-based trajectory model: include/cpe.h, cpe_solve_kinetic (estimate_kinetics, acinoset_opt.py:693-963) */
+cpe_status cpo_solve_kinetic_fixed(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                                   const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
+                                   const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst);
 cpe_status cpo_solve_kinetic(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
                              const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
                              const int32_t* stance, double* q, double* dq, double* ddq, double* positions, double* meas_err,
                              double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
+    return cpo_solve_kinetic_fixed(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, NULL, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
+}
+/* with prescribed net foot forces grf_fixed [N][nf][3] (include/cpe.h, cpe_solve_kinetic_fixed), or NULL */
+cpe_status cpo_solve_kinetic_fixed(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                                   const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
+                                   const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
     int nq = NQ(s);
     for (int p = 0; p < nq; p++) if (s->motion_w[p] != 0.0) return CPE_BAD_ARG;      /* the physics replaces the constant-acceleration cost */
     kin_t K; memset(&K, 0, sizeof(K));
-    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h;
+    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h; K.grf_fix = grf_fixed;
     for (int j = 0; j < s->n_joints; j++) K.nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
     K.nlat = K.nm + K.nc + 3 * K.nf;
     if (K.nlat > CPE_KIN_MAXLAT) return CPE_BAD_ARG;

@@ -96,9 +96,10 @@ def solve_batch(sk, cams, opts, q_init, meas, weight, threads=0, priors=None):
     return int(used), q, its
 
 
-def solve_kinetic(sk, cams, opts, priors, kopts, q_init, meas, weight, stance):
-    """physics-based trajectory model (cpo_solve_kinetic): one sequence, numpy in / out"""
+def solve_kinetic(sk, cams, opts, priors, kopts, q_init, meas, weight, stance, grf_fixed=None):
+    """physics-based trajectory model (cpo_solve_kinetic[_fixed]): one sequence, numpy in / out; grf_fixed [N, nf, 3] = prescribed net foot forces"""
     q_init, meas, weight = _c(q_init), _c(meas), _c(weight)
+    gf = None if grf_fixed is None else _c(grf_fixed)
     stance = np.ascontiguousarray(stance, dtype=np.int32)
     N, Cn, L = weight.shape
     nq, nm, nf = sk.nq, kopts.dyn.n_motors, kopts.dyn.n_feet
@@ -107,9 +108,9 @@ def solve_kinetic(sk, cams, opts, priors, kopts, q_init, meas, weight, stance):
     pos = np.empty((N, L, 3)); me = np.empty((N, Cn, L, 2))
     tau = np.empty((N, nm)); lam = np.empty((N, nc)); grf = np.empty((N, nf, 5)); slack = np.empty((N, nq))
     st = abi.Stats(); ks = abi.KineticStats()
-    rc = lib().cpo_solve_kinetic(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, C.byref(kopts), N,
-                                 _p(q_init), _p(meas), _p(weight), stance.ctypes.data_as(C.POINTER(C.c_int32)), _p(q), _p(dq), _p(ddq), _p(pos), _p(me),
-                                 _p(tau), _p(lam), _p(grf), _p(slack), C.byref(st), C.byref(ks))
+    rc = lib().cpo_solve_kinetic_fixed(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, C.byref(kopts), N,
+                                       _p(q_init), _p(meas), _p(weight), stance.ctypes.data_as(C.POINTER(C.c_int32)), _p(gf), _p(q), _p(dq), _p(ddq), _p(pos), _p(me),
+                                       _p(tau), _p(lam), _p(grf), _p(slack), C.byref(st), C.byref(ks))
     return dict(status=rc, q=q, dq=dq, ddq=ddq, positions=pos, meas_err=me, tau=tau, lam=lam, grf=grf, slack=slack, stats=st, kstats=ks)
 
 

@@ -69,6 +69,37 @@ def test_short_gallops_match_oracle(oracle, gpu_handle_factory):
         assert ks.max_slack < ko.slack_bound and ks.max_violation < 1e-4
 
 
+def test_prescribed_foot_forces_match_oracle(oracle, gpu_handle_factory):
+    """cpe_solve_kinetic_fixed (estimate_kinetics(joint_estimation=False, fix_grf=True), acinoset_opt.py:813-838): 90 % of the forces of the
+    joint estimate, prescribed: HIP and oracle take the same path and report the forces as given"""
+    B, N = 2, 30
+    sk = skeleton.without_motion_model(skeleton.build_skeleton("phantom", 24))
+    cams = synth.make_cameras(6)
+    opts = abi.default_options(120.0); opts.tol_cost, opts.max_iter = 1e-8, 400
+    ko = abi.default_kinetic_options(skeleton.dyn_options("phantom"), 120.0)
+    d = synth.make_gallop_batch(sk, cams, B=B, N=N, seed=4321, init_noise=0.002)
+    h0 = gpu_handle_factory(sk, cams, opts)
+    free = h0.solve_kinetic_host(ko, d["q_init"], d["meas"], d["weight"], d["stance"])
+    g0 = free["grf"]
+    fixed = 0.9 * np.stack([g0[..., 0], g0[..., 1] - g0[..., 3], g0[..., 2] - g0[..., 4]], axis=-1)       # net (z, x, y), body weights
+    h = gpu_handle_factory(sk, cams, opts)
+    # warm start from the joint estimate, as the reference's flow has it (a cold start with given forces crawls: the trajectory alone has to
+    # absorb the mismatch, 400 iterations are not enough -- in both implementations)
+    r = h.solve_kinetic_host(ko, free["q"], d["meas"], d["weight"], d["stance"], grf_fixed=fixed)
+    for b in range(B):
+        ro = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"][b], d["meas"][b], d["weight"][b], d["stance"][b], grf_fixed=fixed[b])
+        st, so = r["stats"][b], ro["stats"]
+        assert st.status == ro["status"] and st.status in (abi.OK, abi.MAX_ITER)      # (a stiff problem: one of the two sequences uses all 400 iterations, in both)
+        assert abs(st.iterations - so.iterations) <= 2 and st.outer == so.outer
+        assert abs(st.cost - so.cost) < 1e-6 * abs(so.cost)
+        assert np.sqrt(((r["positions"][b] - ro["positions"]) ** 2).sum(-1).mean()) < 1e-4
+        assert np.abs(r["tau"][b] - ro["tau"]).max() < 1e-3 and np.abs(r["slack"][b] - ro["slack"]).max() < 1e-4
+        g = r["grf"][b]                                                       # [N, 4, 5] = z, +x, +y, -x, -y
+        assert np.abs(g[2:, :, 0] - fixed[b, 2:, :, 0]).max() < 1e-12 and np.abs((g[2:, :, 1] - g[2:, :, 3]) - fixed[b, 2:, :, 1]).max() < 1e-12
+        assert np.abs(g - ro["grf"]).max() < 1e-12
+        assert np.abs(r["tau"][b] - free["tau"][b]).max() > 1e-3              # other forces: other torques
+
+
 def test_200_frame_gallop_matches_oracle_within_1mm(oracle, gpu_handle_factory):
     """VERDICT r1 item 1 / SURVEY 8d cfg4: N = 200, rotary gallop at 3 Hz, 12-frame stance, phantom skeleton, warm-started from the
     kinematic solve.  HIP and oracle reach the same trajectory: marker RMSE < 1 mm (BASELINE.json's bar), same status; and the equations of
@@ -121,6 +152,35 @@ def test_estimate_kinetics_end_to_end_from_files(tmp_path, gpu_handle_factory):
     assert np.all(est2.kinetic["stance"] == st)
     feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
     assert np.abs(d["positions"][2:, feet, 2][st[2:] == 1]).max() < 0.1 + 1e-3       # planted paws stay within the foot-height tolerance
+    # ---- the kinetic-dataset driver's branch (run_dataset.py:1092-1140): the forces are PRESCRIBED from a per-frame table.  Here: the forces the
+    # joint estimate found for the first contact of every foot, written as grf/data_synth.csv beside a contact file with the planted windows
+    import json
+    from cheetah_pose_estimation_amd import contacts as ct
+    grf_dir = os.path.join(est2.params.data_dir, "grf")
+    with open(os.path.join(est2.params.data_dir, "metadata.json")) as fh:
+        md = json.load(fh)
+    cj = {"start_frame": 4, "end_frame": 52, "contacts": md["contacts"]}
+    with open(os.path.join(grf_dir, "autogen-contact.json"), "w") as fh:
+        json.dump(cj, fh)
+    g = est2.kinetic["grf"]                                                          # [48, 4, 5] = z, +x, +y, -x, -y
+    plates = {}
+    for k, foot in enumerate(skeleton.FEET):
+        rec = cj["contacts"].get(f"{foot}_foot")
+        if rec:
+            plates[int(rec[0][2]) - 1] = np.stack([g[:, k, 1] - g[:, k, 3], 0.0 * g[:, k, 0], g[:, k, 0]], axis=1)      # (Fx, Fy, Fz) per frame
+    ct.write_synth_grf(os.path.join(grf_dir, "data_synth.csv"), plates)
+    gz, gxy = E.grf_profile(E.load_force_table(os.path.join(grf_dir, "data_synth.csv")), cj, 48)
+    assert gz.shape == (48, 4) and gxy.shape == (48, 4, 4) and (gz > 0).sum() > 10 and np.all(gz[47] == 0.0)        # the reference's loop stops one frame short
+    assert np.all((gxy > 0).sum(-1) <= 1)                                            # one polygon side at most (the largest positive component)
+    with pytest.raises(NotImplementedError):
+        E.estimate_kinetics(est2, joint_estimation=False, fix_grf=False, synthesised_grf=True, solver_output=False)
+    ok2 = E.estimate_kinetics(est2, init_torques=True, init_prev_kinematic_solution=True, solver_output=False, auto=True, synthesised_grf=True,
+                              joint_estimation=False, fix_grf=True, ground_constraint=True, out_fname="fte_fixed")
+    r2 = est2.result
+    assert r2["stats"][0].status in (abi.OK, abi.MAX_ITER) and isinstance(ok2, bool)
+    assert np.abs(r2["grf"][0][:, :, 0] - gz).max() < 1e-12 or np.abs(r2["grf"][0][2:, :, 0] - gz[2:]).max() < 1e-12   # reported as prescribed (nodes 0, 1 carry no dynamics)
+    assert np.sqrt(((r2["positions"][0] - truth) ** 2).sum(-1).mean()) < 0.03
+    assert set(est2.synthesised_grf) == {f"{f}_foot" for f in skeleton.FEET}
 
 
 def test_gpu_kinematics_reproduce_the_reference_stored_contact_json(gpu_handle_factory):

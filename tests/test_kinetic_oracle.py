@@ -131,6 +131,29 @@ def test_short_solve_respects_the_contact_rules(oracle):
     assert np.abs(r["slack"][:2]).max() == 0.0 and np.abs(r["tau"][:2]).max() == 0.0
 
 
+def test_prescribed_foot_forces(oracle):
+    """estimate_kinetics(joint_estimation=False, fix_grf=True) (acinoset_opt.py:813-838): the foot forces are given, only torques and joint
+    constraint forces stay unknowns of a node.  Prescribing the forces of the joint estimate reproduces that estimate (its stationarity in the
+    other unknowns does not change); prescribing other forces moves the torques and the equation-of-motion error, never the reported forces."""
+    sk, cams, opts, ko, d = _problem(12, n_cams=6, init_noise=0.02)
+    kin = oracle.solve(skeleton.build_skeleton("phantom", 24), cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+    opts.tol_cost, opts.max_iter = 1e-9, 400
+    free = oracle.solve_kinetic(sk, cams, opts, None, ko, kin["q"], d["meas"][0], d["weight"][0], d["stance"][0])
+    g = free["grf"]
+    net = np.stack([g[..., 0], g[..., 1] - g[..., 3], g[..., 2] - g[..., 4]], axis=-1)       # (z, x, y) in body weights
+    fix = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"], d["meas"][0], d["weight"][0], d["stance"][0], grf_fixed=net)
+    assert fix["status"] == abi.OK
+    assert np.abs(fix["grf"] - g).max() < 1e-12                                              # reported as prescribed
+    assert np.sqrt(((fix["positions"] - free["positions"]) ** 2).sum(-1).mean()) < 1e-4
+    assert np.abs(fix["tau"] - free["tau"]).max() < 1e-2 * max(1.0, np.abs(free["tau"]).max())
+    # half the forces: the equations of motion can no longer be met as well, and the forces stay what was prescribed
+    half = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"], d["meas"][0], d["weight"][0], d["stance"][0], grf_fixed=0.5 * net)
+    on = d["stance"][0] == 1
+    assert np.abs(half["grf"][..., 0] - 0.5 * net[..., 0])[2:][on[2:]].max() < 1e-12 and np.all(half["grf"][~on] == 0.0)
+    assert half["kstats"].cost_eom > 1.2 * fix["kstats"].cost_eom and half["stats"].cost > fix["stats"].cost
+    assert half["kstats"].max_violation < 1e-3                                               # height / slip rules of the stance frames still hold
+
+
 def test_stored_contact_windows_become_stance_flags():
     """the reference's own stored `autogen-contact.json` of 2019_03_07/phantom/run (tests/golden/contacts_pin.npz holds its numbers):
     windows of 13 frames (12-frame stance at 120 fps, both ends included as in acinoset_opt.py:787-798) turn into the stance table"""
