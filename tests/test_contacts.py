@@ -230,3 +230,35 @@ def test_contact_heuristic_reproduces_the_reference_stored_json(oracle):
         Z2 = dict(Z); Z2["ground_offset"] = float(Z["ground_offset"]) + shift
         (c2, _), _ = _detect_in_fitted_frame(Z2, pos, vel)
         assert [c2[n][0][:2] for n in names] == [[168, 180], [157, 169], [155, 167], [144, 156]]
+
+
+def test_contact_heuristic_on_a_second_stored_run(oracle):
+    """Second sequence, other animal, other frame rate: `2017_08_29/top/jules/run1_1` (90 fps, 30 frames), fixture
+    tests/golden/contacts_pin_jules.npz (tools/pin_contacts_from_csv.py ... stance 90; worst pixel error 1.9e-5).  The run is short and
+    its ends dip below the stance height, so the ground plane is fitted through the lowest interior minimum of every paw's height trace.
+    Stored JSON: start 53, end 83, HFL [58, 64] leading, HFR [54, 60] trailing, HBL [69, 75] trailing, HBR [72, 78] leading.  Three
+    windows and all four labels are reproduced exactly; HFR's two lowest frames differ by 5e-5 m in the fitted frame, so its window is
+    pinned to within one frame (which of the two is lower is decided by the unshipped calibration's true ground plane)."""
+    import os
+    from cheetah_pose_estimation_amd import skeleton
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "contacts_pin_jules.npz"))
+    q, fps = Z["q"], float(Z["fps"])
+    assert fps == 90.0 and q.shape[0] == 30 and int(Z["start_frame"]) == 53 and int(Z["end_frame"]) == 83
+    dq = np.zeros_like(q); dq[1:] = (q[1:] - q[:-1]) * fps; dq[0] = dq[1]
+    sk = skeleton.build_skeleton("jules", 24)
+    pos = oracle.markers(sk, q)
+    vel = np.array([np.einsum("ldp,p->ld", oracle.markers_jac(sk, q[n])[1], dq[n]) for n in range(q.shape[0])])
+    up, off = Z["ground_normal"], float(Z["ground_offset"])
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    names = [f"{f}_foot" for f in skeleton.FEET]
+    speed = float(np.linalg.norm(np.diff(pos.mean(1), axis=0) * fps, axis=1).mean())
+    assert ct.stance_frames(speed, fps) == 7                                     # every stored window spans 7 frames
+    for shift in (-0.02, 0.0, 0.02):
+        contacts, by_height = ct.contact_detection(pos[:, feet] @ up - off - shift, vel[:, feet] @ up, names, 53, speed, fps)
+        for i, n in enumerate(names):
+            assert len(contacts[n]) == 1 == int(Z["n_windows"][i])
+            assert contacts[n][0][3] == str(Z["labels"][i]), (n, contacts[n])
+            d = np.array(contacts[n][0][:2]) - Z["windows"][i]
+            assert d[0] == d[1] and abs(int(d[0])) <= (1 if n == "HFR_foot" else 0), (n, contacts[n], Z["windows"][i])
+            if shift == 0.02:                                                    # the below-threshold runs measure the ground offset itself: 2 cm lower matches the stored ones to a frame
+                assert np.abs(np.array(by_height[n][0][:2]) - Z["windows_height_only"][i]).max() <= 1, (n, by_height[n])

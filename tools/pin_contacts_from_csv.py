@@ -23,7 +23,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from cheetah_pose_estimation_amd import skeleton, synth  # noqa: E402
 import pin_fk_from_csv as P  # noqa: E402  (project, rodrigues)
 
-SEQ = "2019_03_07/phantom/run"
+# usage: pin_contacts_from_csv.py [sequence animal camera_fixture monocular_dir output_fixture plane fps]
+#   plane = "lowest": ground plane through the four lowest positions of every paw (long runs: every paw has a clean stance);
+#   plane = "stance": through the lowest interior local minimum of every paw's height trace (short runs whose ends dip below the stance height)
+_A = sys.argv[1:] + ["2019_03_07/phantom/run", "phantom", "fk_csv_pin.npz", "fte_kinematic_1", "contacts_pin.npz", "lowest", "120"][len(sys.argv) - 1:]
+SEQ, ANIMAL, CAM_FIXTURE, MONO, OUT, PLANE, FPS = _A[:7]
 SRC = f"/root/reference/data/test_set/{SEQ}"
 
 
@@ -36,11 +40,11 @@ def load_uv(sub):
 
 
 def main():
-    Z = np.load(os.path.join(ROOT, "tests", "golden", "fk_csv_pin.npz"))
+    Z = np.load(os.path.join(ROOT, "tests", "golden", CAM_FIXTURE))
     cams = Z["cams"]
-    uv, idx0 = load_uv("fte_kinematic_1")
+    uv, idx0 = load_uv(MONO)
     N = uv.shape[0]
-    sk = skeleton.build_skeleton("phantom", 24)
+    sk = skeleton.build_skeleton(ANIMAL, 24)
     lay = synth.leg_layout(sk)
     ind = skeleton.independent_dofs(sk)
     trunk = [p for p in ind if not any(p == 3 + 3 * c + 1 for c, _ in lay)]       # independent Euler dofs that are not leg pitches
@@ -88,7 +92,15 @@ def main():
     up = np.array([0, 0, 1.0]); off = 0.0
     for _ in range(5):
         hgt = pos[:, feet] @ up
-        pts = np.concatenate([pos[np.argsort(hgt[:, k])[:4], feet[k]] for k in range(4)])
+        if PLANE == "stance":
+            pts = []
+            for k in range(4):
+                h = hgt[:, k]
+                loc = [n for n in range(1, N - 1) if h[n] < h[n - 1] and h[n] <= h[n + 1]]
+                pts.append(pos[min(loc, key=lambda n: h[n]), feet[k]])
+            pts = np.array(pts)
+        else:
+            pts = np.concatenate([pos[np.argsort(hgt[:, k])[:4], feet[k]] for k in range(4)])
         c = pts.mean(0)
         w = np.linalg.svd(pts - c)[2][-1]
         up = w if w @ up > 0 else -w
@@ -102,9 +114,9 @@ def main():
     win = np.array([[cj["contacts"][n][0][0], cj["contacts"][n][0][1]] if cj["contacts"][n] else [-1, -1] for n in names])
     lab = np.array([cj["contacts"][n][0][3] if cj["contacts"][n] else "" for n in names])
     win2 = np.array([[cj2["contacts"][n][0][0], cj2["contacts"][n][0][1]] if cj2["contacts"][n] else [-1, -1] for n in names])
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "contacts_pin.npz"), uv=uv, q=q_out, cams=cams, ground_normal=up, ground_offset=off,
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", OUT), uv=uv, q=q_out, cams=cams, ground_normal=up, ground_offset=off,
                         start_frame=cj["start_frame"], end_frame=cj["end_frame"], windows=win, labels=lab, windows_height_only=win2,
-                        first_index=idx0, worst_px=worst, n_windows=np.array([len(cj["contacts"][n] or []) for n in names]))
+                        first_index=idx0, worst_px=worst, fps=float(FPS), plane=PLANE, seq=SEQ, animal=ANIMAL, n_windows=np.array([len(cj["contacts"][n] or []) for n in names]))
     print("stored windows", win.tolist(), lab.tolist(), "height-only", win2.tolist())
 
 
