@@ -350,12 +350,41 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
                 m.gg_code[m.gg_cnt[a]++][a] = (uint16_t)((m.mcol_off[l] + i) | (l << 8));
             }
     }
+    {   // per-lane tables of k_frame_normal with resolved indices (see cpe_model.h)
+        m.hk_n = 0;
+        for (int r = 0; r < m.ndep; r++) {
+            const int j = m.dep_joint[r];
+            if (m.joint_kind[j] != CPE_JOINT_HOOKE_YZ || m.srow[r] < 0) continue;
+            for (int jc = 0; jc < m.scol_n[r]; jc++) {
+                if (m.hk_n >= 64) return fail(CPE_BAD_ARG, "more than 64 entries in the hooke rows of S");
+                const int ps = m.trunk_slot[m.joint_parent[j]], cs = m.trunk_slot[m.joint_child[j]];
+                if (ps < 0 || cs < 0 || ps >= 64 || cs >= 64) return fail(CPE_BAD_ARG, "hooke joint between leg links");
+                m.hk_w[m.hk_n][0] = ps | (cs << 6) | ((m.hk_kind[r][jc] & 3) << 12) | ((m.hk_ang[r][jc] & 3) << 14) | ((m.dep_level[r] & 1) << 16);
+                m.hk_w[m.hk_n][1] = (m.hk_chain[r][jc] + 1) | ((m.srow[r] * CPE_MAX_SCOL + jc) << 16);
+                m.hk_n++;
+            }
+        }
+        m.hj_n = 0;
+        for (int j = 0; j < s->n_joints; j++)
+            if (m.joint_kind[j] == CPE_JOINT_HOOKE_YZ) {
+                if (m.hj_n >= 64) return fail(CPE_BAD_ARG, "more than 64 hooke joints");
+                m.fn_lane[m.hj_n++][0] = m.joint_parent[j] | (m.joint_child[j] << 8) | ((m.dep_of_q[3 + 3 * m.joint_parent[j]] >= 0 ? 1 : 0) << 16);
+            }
+        for (int t = 0; t < 4 * m.n_trunk && t < 64; t++) m.fn_lane[t][1] = m.trunk_link[t >> 2];     // (nrev <= 16 and sv_n <= 48 by the table sizes)
+        for (int r = 0; r < m.nrev; r++) m.fn_lane[r][2] = m.rev_body[r] | (m.rev_child[r] << 8) | (m.trunk_slot[m.rev_body[r]] << 16);
+        for (int t = 0; t < m.sv_n; t++) m.fn_lane[t][3] = m.sv_kind[t] | (m.sv_cnt[t] << 2) | (m.sv_rev[t][0] << 4) | (m.sv_rev[t][1] << 10) | (m.sv_rev[t][2] << 16);
+        for (int l = 0; l < L; l++) {
+            for (int i = 0; i < m.pc_len[l]; i++) m.pc_off[l][i] = 36 * m.trunk_slot[m.pc_link[l][i]];
+            m.pw_off[l] = m.pw_id[l] >= 0 ? 36 * m.trunk_slot[m.pw_body[l]] : 0;
+        }
+    }
     for (int bnd = 0; bnd < s->n_bounds; bnd++) {
         const int a = s->bound_a[bnd], bb = s->bound_b[bnd];
         if (a < 0 || a >= nq || bb >= nq || m.u_of_q[a] < 0 || (bb >= 0 && m.u_of_q[bb] < 0))
             return fail(CPE_BAD_ARG, "bounds must act on independent dofs");
         m.bound_ua[bnd] = m.u_of_q[a]; m.bound_ub[bnd] = bb < 0 ? -1 : m.u_of_q[bb];
         m.bound_lo[bnd] = s->bound_lo[bnd]; m.bound_up[bnd] = s->bound_up[bnd];
+        m.bnd_q[bnd] = a | ((bb + 1) << 8);
     }
     return CPE_OK;
 }
@@ -367,7 +396,9 @@ static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0, bool
     // g (and, unless the plain variant writes H straight to HBM, H | g) overlay the S rows, which are dead once Dp is built
     const bool plain = gmm_k == 0 && !shutter;
     size_t ov = CPE_MAX_SCOL * m.n_srow, hg = plain ? m.nu : m.nu * m.nu + m.nu;
-    size_t n = m.ns + 6 * m.nl + 2 * m.nrev + 36 * m.n_trunk + 3 * m.L + 3 * m.sv_n + GAM_STRIDE * m.nrev + (ov > hg ? ov : hg) +
+    size_t camov = 6 * m.nl + 2 * m.nrev + 36 * m.n_trunk;   // sin / cos tables + trunk rotations, later the staged cameras (sizeof(cpe_camera) = 22 doubles each)
+    if (camov < (size_t)22 * m.C) camov = (size_t)22 * m.C;
+    size_t n = m.ns + camov + 3 * m.L + 3 * m.sv_n + GAM_STRIDE * m.nrev + (ov > hg ? ov : hg) +
                9 * m.L + 3 * m.mc_total;
     if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX + gmm_dim * gmm_dim + 2 * gmm_dim * m.nu;
     if (shutter) n += 15 * m.C + 6 * m.L + 6;          // shift | coefficients | rc | Mc per camera, M1 per marker, M2

@@ -114,6 +114,18 @@ struct DevModel {
     // marker position: x + sum_k R_{pc_link} pc_vec + (pw_id >= 0 ? R_{pw_body} dyn[pw_id] : 0)
     int32_t pc_len[CPE_MAX_MARKERS], pc_link[CPE_MAX_MARKERS][CPE_MAX_CHAIN], pw_id[CPE_MAX_MARKERS], pw_body[CPE_MAX_MARKERS];
     double pc_vec[CPE_MAX_MARKERS][CPE_MAX_CHAIN][3];
+    // k_frame_normal's per-lane tables with every index resolved on the host (no table read depends on another one):
+    //   hooke S items, one per lane: w0 = parent slot | child slot << 6 | hk_kind << 12 | hk_ang << 14 | level << 16, w1 = (hk_chain + 1) | Sval index << 16;
+    //   marker chains as offsets into the trunk rotation table (36 * trunk_slot; entries past pc_len: offset 0 and a zero vector);
+    //   bounds as indices into the Euler state: q index of a | (q index of b + 1) << 8
+    //   first-phase words, one int4 per lane: x = hooke joint `lane` (parent | child << 8 | parent's phi dependent << 16; hj_n of them),
+    //   y = trunk link of rotation block `lane` (lane >> 2 indexes trunk_link), z = leg link `lane` (body | child << 8 | body's trunk slot << 16),
+    //   w = dynamic vector `lane` (sv_kind | sv_cnt << 2 | sv_rev[0..2] << 4, 10, 16)
+    int32_t hj_n;
+    alignas(16) int32_t fn_lane[64][4];
+    int32_t hk_n, hk_w[64][2];
+    int32_t pc_off[CPE_MAX_MARKERS][CPE_MAX_CHAIN], pw_off[CPE_MAX_MARKERS];
+    int32_t bnd_q[CPE_MAX_BOUNDS];
     // solver Jacobian slots: dp = Mat(ss_moff) * (ss_vdyn < 0 ? ss_vec : dyn[ss_vdyn]); ss_moff < 0: identity
     int32_t ss_moff[CPE_MAX_SLOTS], ss_vdyn[CPE_MAX_SLOTS];
     double ss_vec[CPE_MAX_SLOTS][3];

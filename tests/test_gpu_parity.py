@@ -532,7 +532,10 @@ def test_solve_short_sequences(N, b, sk25, cams6, oracle, gpu_handle_factory):
         pytest.xfail("flat directions without the motion coupling: the implementations stop apart, at the iteration limit or after different paths")
     assert st.status == rs.status
     assert st.status == abi.OK
-    assert abs(st.iterations - rs.iterations) <= 2
+    # same path: +-2 iterations.  One case, (5, 1), crawls ~110 iterations through a flat region before it converges; there a last-bit
+    # difference in the projection Jacobian (1e-16 relative, round 2: the same kernel before / after a re-ordering took 109 / 94) moves the
+    # stopping iteration by 15 % while cost and positions still agree to the tolerances below
+    assert abs(st.iterations - rs.iterations) <= (2 if rs.iterations < 60 else rs.iterations // 5)
     assert abs(st.cost - rs.cost) < 1e-6 * abs(rs.cost)
     assert np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-5
 
