@@ -102,6 +102,54 @@ __device__ __forceinline__ void project_point(const cpe_camera& c, double px, do
     }
 }
 
+// project_point for a camera staged in LDS as CAMW = 22 doubles in cpe_camera's layout (model word | fx fy cx cy | D[4] | R[9] | t[3] | mult).
+// Same arithmetic in the same order; the camera is read in three instalments -- R, t for the camera-frame point; D for the distortion; R, fx, fy
+// again for the 2x3 derivative -- each through a camera index that an empty `asm` ties to the previous instalment's result, so that the 22 parameters are never live together with the
+// atan / sqrt / division temporaries (read up front from global memory they cost 46 VGPRs and the kernel its third wave per SIMD).
+#define CAMW 22
+static_assert(sizeof(cpe_camera) == CAMW * sizeof(double), "cpe_camera layout");
+__device__ __forceinline__ void project_point_staged(const double* scam, int c, double px, double py, double pz, double& u, double& v, double* G) {
+    const double* cam = scam + CAMW * c;
+    const double* cR = cam + 9; const double* ct = cam + 18;
+    const double X0 = cR[0] * px + cR[1] * py + cR[2] * pz + ct[0];
+    const double X1 = cR[3] * px + cR[4] * py + cR[5] * pz + ct[1];
+    double X2 = cR[6] * px + cR[7] * py + cR[8] * pz + ct[2];
+    int c2 = c;
+    asm volatile("" : "+v"(c2), "+v"(X2));                  // the camera index of the second instalment exists only once X2 does
+    const double* cD = scam + CAMW * c2 + 5;
+    const double iz = 1.0 / X2;
+    const double a = X0 * iz, b = X1 * iz;
+    const double r2 = a * a + b * b;
+    const double r = sqrt(r2);
+    double g, dg;
+    if (reinterpret_cast<const int*>(cD - 5)[0] == CPE_CAM_FISHEYE) {
+        const double th = atan(r), t2 = th * th;
+        const double poly = 1.0 + t2 * (cD[0] + t2 * (cD[1] + t2 * (cD[2] + t2 * cD[3])));
+        const double dpoly = 1.0 + t2 * (3.0 * cD[0] + t2 * (5.0 * cD[1] + t2 * (7.0 * cD[2] + t2 * 9.0 * cD[3])));
+        const double den = r + 1e-12, iden = 1.0 / den;
+        g = th * poly * iden;
+        dg = (dpoly / (1.0 + r2) - g) * iden;
+    } else {
+        g = 1.0 + r2 * (cD[0] + r2 * (cD[1] + r2 * cD[2]));
+        dg = r * (2.0 * cD[0] + r2 * (4.0 * cD[1] + r2 * 6.0 * cD[2]));
+    }
+    int c3 = c2;
+    asm volatile("" : "+v"(c3), "+v"(dg));                  // ... and that of the third once the distortion is done
+    const double* cam3 = scam + CAMW * c3; const double* cR3 = cam3 + 9;
+    const double fx = cam3[1], fy = cam3[2];
+    u = fx * a * g + cam3[3];
+    v = fy * b * g + cam3[4];
+    const double k = r > 0.0 ? dg / r : 0.0;
+    const double xa = g + a * a * k, xb = a * b * k, yb = g + b * b * k;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double da = (cR3[j] - a * cR3[6 + j]) * iz;
+        const double db = (cR3[3 + j] - b * cR3[6 + j]) * iz;
+        G[j] = fx * (xa * da + xb * db);
+        G[3 + j] = fy * (xb * da + yb * db);
+    }
+}
+
 // redescending loss rho(s) (acinoset_misc.py:2001-2015): value, d rho/ds, PSD curvature weight.
 // curvature mode 0: max(rho'', rho'(|s|)/|s|, 0); mode 1: max(rho'', 0)   (DESIGN.md "Solver")
 struct LossOut { double rho, d1, cw; };

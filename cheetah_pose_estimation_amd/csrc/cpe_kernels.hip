@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevM
             if (t < CL) {
                 const int c = t / L, l = t - c * L;
                 double u, v, G[6];
-                project_point(cams[c], spos[3 * l], spos[3 * l + 1], spos[3 * l + 2], u, v, G);
+                project_point(cams[c], spos[3 * l], spos[3 * l + 1], spos[3 * l + 2], u, v, G);      // (the staged form, 210 instead of 225 VGPRs, measured 0.8 % slower here: no occupancy step in reach)
                 uv[p] = make_double2(u, v);
                 double2* Gd = reinterpret_cast<double2*>(sG + 6 * t);
                 Gd[0] = make_double2(G[0], G[1]); Gd[1] = make_double2(G[2], G[3]); Gd[2] = make_double2(G[4], G[5]);
