@@ -1196,9 +1196,27 @@ cpe_status cpo_solve_kinetic(const cpe_skeleton* s, const cpe_camera* cams, int 
     return cpo_solve_kinetic_fixed(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, NULL, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
 }
 /* with prescribed net foot forces grf_fixed [N][nf][3] (include/cpe.h, cpe_solve_kinetic_fixed), or NULL */
+static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                                   const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
+                                   const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst);
 cpe_status cpo_solve_kinetic_fixed(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
                                    const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
                                    const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
+    return solve_kinetic_impl(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, grf_fixed, NULL, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
+}
+/* with every torque boxed: tau_box [N][n_motors][2] = (lower, upper) (include/cpe.h, cpe_solve_kinetic_bounded: the reference's module-level
+ * estimate_grf, acinoset_opt.py:966-1048, bounds the torques to +-10 % of a previous solve) */
+cpe_status cpo_solve_kinetic_bounded(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                                   const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
+                                   const int32_t* stance, const double* tau_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
+    return solve_kinetic_impl(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, NULL, tau_box, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
+}
+static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                                   const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
+                                   const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
                                    double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
     int nq = NQ(s);
     for (int p = 0; p < nq; p++) if (s->motion_w[p] != 0.0) return CPE_BAD_ARG;      /* the physics replaces the constant-acceleration cost */
@@ -1211,6 +1229,7 @@ cpe_status cpo_solve_kinetic_fixed(const cpe_skeleton* s, const cpe_camera* cams
     K.Mg = M * ko->dyn.eom.gravity;
     K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
     K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
+    K.tau_box = tau_box; K.mu_tau = (double*)calloc((size_t)N * K.nm * 2 + 1, sizeof(double));
     K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
     K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
     cpe_status rc = solve_impl(s, cams, C, o, pr, N, q_init, meas, weight, q, dq, ddq, positions, meas_err, st, &K);
@@ -1232,7 +1251,7 @@ cpe_status cpo_solve_kinetic_fixed(const cpe_skeleton* s, const cpe_camera* cams
         kst->cost_torque = K.torque; kst->cost_energy = K.energy; kst->cost_eom = K.eom; kst->max_slack = K.max_slack;
         kst->max_base_rows = K.max_base; kst->max_violation = K.max_viol; kst->inner_max = K.inner_max; kst->_pad = 0;
     }
-    free(K.f_cur); free(K.f_try); free(K.mu); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
+    free(K.f_cur); free(K.f_try); free(K.mu); free(K.mu_tau); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
     return rc;
 }
 

@@ -166,3 +166,36 @@ def test_stored_contact_windows_become_stance_flags():
     st = E.stance_from_contacts(cj, 57, 135)
     assert st.shape == (57, 4) and list(st.sum(0)) == [13, 13, 13, 13]
     assert [int(np.flatnonzero(st[:, k])[0]) + 135 for k in range(4)] == [168, 157, 155, 144]          # HFL, HFR, HBL, HBR
+
+
+def _bound_value(v, slack):
+    """acinoset_misc.py:84-90"""
+    v = np.asarray(v, dtype=float)
+    lo = np.where(v > 0, (1 - slack) * v, np.where(v < 0, (1 + slack) * v, -slack))
+    hi = np.where(v > 0, (1 + slack) * v, np.where(v < 0, (1 - slack) * v, slack))
+    return np.stack([lo, hi], axis=-1)
+
+
+def test_torque_boxes(oracle):
+    """cpo_solve_kinetic_bounded (the reference's module-level estimate_grf, acinoset_opt.py:995-1003: every torque within +-10 % of a previous
+    solve).  Boxes around the free solution's own torques leave that solution in place (it is feasible and was optimal without them);
+    boxes around HALF of those torques hold the torques inside them, at the price of a larger equation-of-motion error."""
+    sk, cams, opts, ko, d = _problem(12, n_cams=6, init_noise=0.02)
+    kin = oracle.solve(skeleton.build_skeleton("phantom", 24), cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+    opts.tol_cost, opts.max_iter = 1e-9, 400
+    free = oracle.solve_kinetic(sk, cams, opts, None, ko, kin["q"], d["meas"][0], d["weight"][0], d["stance"][0])
+    box = _bound_value(free["tau"], 0.1)
+    same = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"], d["meas"][0], d["weight"][0], d["stance"][0], tau_box=box)
+    assert same["status"] == abi.OK
+    assert np.sqrt(((same["positions"] - free["positions"]) ** 2).sum(-1).mean()) < 1e-4
+    assert np.abs(same["tau"] - free["tau"]).max() < 1e-2 * max(1.0, np.abs(free["tau"]).max())
+    assert abs(same["stats"].cost - free["stats"].cost) < 1e-4 * free["stats"].cost
+    tight = _bound_value(0.5 * free["tau"], 0.1)
+    held = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"], d["meas"][0], d["weight"][0], d["stance"][0], tau_box=tight)
+    assert held["status"] in (abi.OK, abi.MAX_ITER)
+    t = held["tau"][2:]
+    assert (t >= tight[2:, :, 0] - 1e-5).all() and (t <= tight[2:, :, 1] + 1e-5).all()             # inside the boxes (to the multiplier method's tolerance)
+    assert held["kstats"].max_violation < 1e-5
+    big = np.abs(free["tau"][2:]) > 0.05                                                          # torques that the halved boxes exclude (the model's torques are O(0.1))
+    assert big.any() and (np.abs(t[big]) < 0.56 * np.abs(free["tau"][2:][big])).all()
+    assert held["kstats"].cost_eom > free["kstats"].cost_eom and held["stats"].cost > free["stats"].cost
