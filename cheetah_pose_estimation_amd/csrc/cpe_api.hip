@@ -52,6 +52,7 @@ struct cpe_handle {
     // physics-based model (cpe_solve_kinetic): device options and workspace
     DevKin* dk = nullptr; DevKin hk;
     size_t kws_frames = 0;
+    double *kmut = nullptr;       // multipliers of the torque boxes [F][2 CPE_MAX_MOTORS] (cpe_solve_kinetic_bounded)
     double *fbuf = nullptr, *kmu = nullptr, *Jbuf = nullptr, *Abuf = nullptr, *pieces = nullptr, *gTb = nullptr, *dstat = nullptr, *slackb = nullptr,
            *Tbuf = nullptr, *gk = nullptr, *Bk = nullptr, *Hk = nullptr;
     int* pmeta = nullptr;
@@ -492,9 +493,9 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
 }
 
 static void free_kws(cpe_handle* h) {
-    void* ptrs[] = {h->fbuf, h->kmu, h->Jbuf, h->Abuf, h->pieces, h->gTb, h->dstat, h->slackb, h->Tbuf, h->gk, h->Bk, h->Hk, h->pmeta};
+    void* ptrs[] = {h->kmut, h->fbuf, h->kmu, h->Jbuf, h->Abuf, h->pieces, h->gTb, h->dstat, h->slackb, h->Tbuf, h->gk, h->Bk, h->Hk, h->pmeta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->fbuf = h->kmu = h->Jbuf = h->Abuf = h->pieces = h->gTb = h->dstat = h->slackb = h->Tbuf = h->gk = h->Bk = h->Hk = nullptr; h->pmeta = nullptr;
+    h->kmut = h->fbuf = h->kmu = h->Jbuf = h->Abuf = h->pieces = h->gTb = h->dstat = h->slackb = h->Tbuf = h->gk = h->Bk = h->Hk = nullptr; h->pmeta = nullptr;
     h->kws_frames = 0;
 }
 
@@ -1055,7 +1056,7 @@ void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kin
     o->inner_iterations = 30; o->_pad = 0;
 }
 
-static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const double* grf_fix = nullptr) {
+static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const double* grf_fix = nullptr, const double* tau_box = nullptr) {
     const DevModel& m = h->hm;
     DevKin& K = h->hk;
     memset(&K, 0, sizeof(K));
@@ -1082,6 +1083,7 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
     K.Mg = mt * d.eom.gravity; K.h = h->opts.h; K.ih = 1.0 / h->opts.h;
     for (int i = 0; i < m.nl; i++) { uint32_t mask = 0; for (int j = 0; j < m.nl; j++) { int a = j; while (a >= 0 && a != i) a = m.parent[a]; if (a == i) mask |= 1u << j; } K.sub_mask[i] = mask; }
     K.grf_fix = grf_fix;
+    K.tau_box = tau_box; K.mu_tau = h->kmut;            // (the workspace is sized before this is called)
     if (!h->dk) HIPCHK(hipMalloc(&h->dk, sizeof(DevKin)));
     HIPCHK(hipMemcpyAsync(h->dk, &K, sizeof(DevKin), hipMemcpyHostToDevice, h->stream));
     return CPE_OK;
@@ -1101,6 +1103,7 @@ static cpe_status ensure_kws(cpe_handle* h, int B, int N) {
     const int BB = CPE_NX * CPE_NX;
     HIPCHK(hipMalloc(&h->fbuf, sizeof(double) * 2 * F * KIN_LS));
     HIPCHK(hipMalloc(&h->kmu, sizeof(double) * F * 4 * KIN_MU));
+    HIPCHK(hipMalloc(&h->kmut, sizeof(double) * F * 2 * CPE_MAX_MOTORS));
     HIPCHK(hipMalloc(&h->Jbuf, sizeof(double) * F * KIN_JSTRIDE));
     HIPCHK(hipMalloc(&h->Abuf, sizeof(double) * F * CPE_MAX_NQ * KIN_LS));
     HIPCHK(hipMalloc(&h->pieces, sizeof(double) * 2 * F * KIN_PIECE));
@@ -1135,10 +1138,27 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
     return cpe_solve_kinetic_fixed(h, opt, B, N, q_init, meas, weight, stance, nullptr, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
 }
 
+static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                     const double* weight, const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq,
+                                     double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                     cpe_kinetic_stats* kstats);
 cpe_status cpe_solve_kinetic_fixed(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
                                    const double* weight, const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq,
                                    double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                                    cpe_kinetic_stats* kstats) {
+    return solve_kinetic_impl(h, opt, B, N, q_init, meas, weight, stance, grf_fixed, nullptr, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
+}
+cpe_status cpe_solve_kinetic_bounded(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                     const double* weight, const int32_t* stance, const double* tau_box, double* q, double* dq, double* ddq,
+                                     double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                     cpe_kinetic_stats* kstats) {
+    if (!tau_box) return fail(CPE_BAD_ARG, "null argument");
+    return solve_kinetic_impl(h, opt, B, N, q_init, meas, weight, stance, nullptr, tau_box, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
+}
+static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                     const double* weight, const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq,
+                                     double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                     cpe_kinetic_stats* kstats) {
     if (!h || !opt || !q_init || !meas || !weight || !stance || !q) return fail(CPE_BAD_ARG, "null argument");
     if ((dq == nullptr) != (ddq == nullptr)) return fail(CPE_BAD_ARG, "dq and ddq must be given together");
     if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
@@ -1147,11 +1167,11 @@ cpe_status cpe_solve_kinetic_fixed(cpe_handle* h, const cpe_kinetic_options* opt
     if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
     if (h->pb != 3) return fail(CPE_BAD_ARG, "the physics-based model runs on the half-bandwidth-3 solver");
     HIPCHK(hipSetDevice(h->device));
-    cpe_status s = build_kin(h, opt, grf_fixed);
-    if (s != CPE_OK) return s;
-    s = ensure_ws(h, B, N);
+    cpe_status s = ensure_ws(h, B, N);
     if (s != CPE_OK) return s;
     s = ensure_kws(h, B, N);
+    if (s != CPE_OK) return s;
+    s = build_kin(h, opt, grf_fixed, tau_box);
     if (s != CPE_OK) return s;
     const DevModel& m = h->hm;
     const size_t Fw = F;
@@ -1160,6 +1180,7 @@ cpe_status cpe_solve_kinetic_fixed(cpe_handle* h, const cpe_kinetic_options* opt
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     HIPCHK(hipMemsetAsync(h->fbuf, 0, sizeof(double) * 2 * F * KIN_LS, h->stream));
     HIPCHK(hipMemsetAsync(h->kmu, 0, sizeof(double) * F * 4 * KIN_MU, h->stream));
+    if (tau_box) HIPCHK(hipMemsetAsync(h->kmut, 0, sizeof(double) * F * 2 * CPE_MAX_MOTORS, h->stream));
     LmParams prm;
     prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
     prm.bound_tol = h->opts.bound_tol; prm.max_outer = h->opts.max_outer; prm.max_iter = h->opts.max_iter;

@@ -384,6 +384,16 @@ cpe_status cpe_solve_kinetic_fixed(cpe_handle* h, const cpe_kinetic_options* opt
                                    double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                                    cpe_kinetic_stats* kstats);
 
+/* the same with every TORQUE BOXED: the reference's module-level estimate_grf (acinoset_opt.py:966-1048, called by run_dataset.py:1138 as the last
+ * stage of the kinetic-dataset pipeline) re-solves the physics-based model from the previous solve with `Tc.bounds = bound_value(init_tau, 0.1)` (:995-1003),
+ * the foot forces free where the measured force plates saw a contact and zero elsewhere.  tau_box [B][N][n_motors][2] = (lower, upper), device pointer.
+ * The boxes are augmented-Lagrangian rows of the node (penalty kappa_force, multipliers updated with the others); inside the node solve their active
+ * set is iterated to a fixed point around the exact elimination of torques and constraint forces.  `stance` carries the measured contact pattern. */
+cpe_status cpe_solve_kinetic_bounded(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                     const double* weight, const int32_t* stance, const double* tau_box, double* q, double* dq, double* ddq,
+                                     double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                     cpe_kinetic_stats* kstats);
+
 /* diagnostic building block of cpe_solve_kinetic (as cpe_eval_normal is of cpe_solve): ONE evaluation of the physics terms of every node at
  * Euler q, multipliers zero, forces from a cold start -- what ASL hands IPOPT per node for the constraints of make_pyomo_model(include_eom_slack=True)
  * (acinoset_opt.py:510-514) after the node forces are minimised out.  Device pointers, each may be NULL: f [B][N][64] node forces (tau | lambda |

@@ -200,3 +200,52 @@ def test_gpu_kinematics_reproduce_the_reference_stored_contact_json(gpu_handle_f
     # and the stored 2D files of that solution are reproduced by the HIP projection (six cameras x 57 frames x 24 markers)
     uv = h.reproject_host(pos)
     assert np.abs(uv[0] - Z["uv"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_torque_boxes_match_oracle(oracle, gpu_handle_factory):
+    """cpe_solve_kinetic_bounded (the reference's module-level estimate_grf, acinoset_opt.py:966-1048: torques within +-10 % of a previous solve).
+    Boxes around 60 % of the joint estimate's torques are active for most motors: HIP (active set iterated around the exact elimination)
+    and oracle (semismooth Newton on all node forces) reach the same constrained minimiser; boxes around the estimate itself leave it in place."""
+    B, N = 2, 30
+    sk = skeleton.without_motion_model(skeleton.build_skeleton("phantom", 24))
+    cams = synth.make_cameras(6)
+    opts = abi.default_options(120.0); opts.tol_cost, opts.max_iter = 1e-8, 400
+    ko = abi.default_kinetic_options(skeleton.dyn_options("phantom"), 120.0)
+    d = synth.make_gallop_batch(sk, cams, B=B, N=N, seed=4321, init_noise=0.002)
+    h0 = gpu_handle_factory(sk, cams, opts)
+    free = h0.solve_kinetic_host(ko, d["q_init"], d["meas"], d["weight"], d["stance"])
+
+    def boxes(t, slack=0.1):                                                     # acinoset_misc.bound_value
+        lo = np.where(t > 0, (1 - slack) * t, np.where(t < 0, (1 + slack) * t, -slack))
+        hi = np.where(t > 0, (1 + slack) * t, np.where(t < 0, (1 - slack) * t, slack))
+        return np.stack([lo, hi], axis=-1)
+
+    h = gpu_handle_factory(sk, cams, opts)
+    same = h.solve_kinetic_host(ko, free["q"], d["meas"], d["weight"], d["stance"], tau_box=boxes(free["tau"]))
+    for b in range(B):                                                           # (sequence 1 of this seed is the stiff one: 400 iterations with or without boxes)
+        assert same["stats"][b].status == free["stats"][b].status
+        if free["stats"][b].status == abi.OK:
+            assert np.abs(same["tau"][b] - free["tau"][b]).max() < 1e-2 * max(1.0, np.abs(free["tau"][b]).max())
+            assert np.sqrt(((same["positions"][b] - free["positions"][b]) ** 2).sum(-1).mean()) < 1e-4
+        else:                                                                    # the crawl simply goes on for another 400 iterations
+            assert same["stats"][b].cost <= free["stats"][b].cost * (1 + 1e-6)
+    tight = boxes(0.6 * free["tau"])
+    r = h.solve_kinetic_host(ko, free["q"], d["meas"], d["weight"], d["stance"], tau_box=tight)
+    converged = 0
+    for b in range(B):
+        ro = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"][b], d["meas"][b], d["weight"][b], d["stance"][b], tau_box=tight[b])
+        st, so = r["stats"][b], ro["stats"]
+        assert st.status == ro["status"] and st.status in (abi.OK, abi.MAX_ITER)
+        ok = st.status == abi.OK                                                 # at the iteration limit both stop somewhere along the same crawl
+        converged += ok
+        assert abs(st.iterations - so.iterations) <= max(2, so.iterations // 10) and st.outer == so.outer
+        assert abs(st.cost - so.cost) < (1e-5 if ok else 1e-3) * abs(so.cost)
+        assert np.sqrt(((r["positions"][b] - ro["positions"]) ** 2).sum(-1).mean()) < (1e-5 if ok else 1e-3)
+        assert np.abs(r["tau"][b] - ro["tau"]).max() < (1e-4 if ok else 1e-2)
+        t, tol = r["tau"][b][2:], (1e-4 if ok else 1e-2)
+        assert (t >= tight[b, 2:, :, 0] - tol).all() and (t <= tight[b, 2:, :, 1] + tol).all()
+        assert r["kstats"][b].cost_eom > free["kstats"][b].cost_eom
+        if ok:
+            assert r["kstats"][b].max_violation < 1e-4
+    assert converged >= 1
