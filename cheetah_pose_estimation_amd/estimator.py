@@ -755,7 +755,92 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     return ok
 
 
-def estimate_grf(estimator, *args, **kwargs) -> bool:
-    raise NotImplementedError("GRF re-optimisation of the kinetic-dataset trajectory (acinoset_opt.py:966-1048: torques boxed to +-10 % of a previous "
-                              "solve, contact windows from force-plate files the reference does not ship) is not built; the physics-based solve is "
-                              "estimate_kinetics, the per-frame fit (row a13) is CheetahEstimator.estimate_grf")
+def bound_value(val, slack_percentage: float) -> np.ndarray:
+    """`misc.bound_value` (acinoset_misc.py:84-90), vectorised: [..., 2] = (lower, upper) -- within `slack_percentage` of the value on its own
+    side of zero, (-slack, +slack) for a value of exactly zero"""
+    v = np.asarray(val, dtype=np.float64)
+    lo = np.where(v > 0, (1 - slack_percentage) * v, np.where(v < 0, (1 + slack_percentage) * v, -slack_percentage))
+    hi = np.where(v > 0, (1 + slack_percentage) * v, np.where(v < 0, (1 - slack_percentage) * v, slack_percentage))
+    return np.stack([lo, hi], axis=-1)
+
+
+def estimate_grf(estimator: CheetahEstimator, solver_output: bool = True, out_dir_prefix: Optional[str] = None,
+                 options: Optional[abi.Options] = None, kinetic_options: Optional[abi.KineticOptions] = None) -> bool:
+    """Same signature and meaning as the module-level acinoset_opt.estimate_grf (acinoset_opt.py:966-1048), the last stage of the kinetic-dataset
+    pipeline (run_dataset.py:1125-1138): the physics-based model is solved again from the stored `fte_kinetic/fte.pickle` -- trajectory as the
+    starting point, every torque within 10 % of its stored value (`Tc.bounds = bound_value(init_tau, 0.1)`, :995-1003) -- with the ground-reaction
+    forces FREE where the measured force plates saw the foot on the ground and zero elsewhere (:1005-1017), the feet within 3 cm of the ground
+    during those contacts, no pose prior, cost = measurement + torque + 0.1 fps^-2 smoothing + 10e3 slack (:1019-1026).  Runs on the GPU
+    (cpe_solve_kinetic_bounded); writes `fte_grf/`.
+    Contact pattern: the reference takes the non-zero entries of `get_grf_profile(..., synthetic_data=False)`, i.e. the frames of each foot's FIRST
+    window in `metadata.json` (frames 0 .. N-2) at which the resampled plate signal is non-zero; with a per-frame CSV twin `grf/data.csv` of that
+    table (the reference ships `grf/data.h5` at 3.5 kHz, which needs PyTables and a resampling step that are not reproduced here) the same rule is
+    applied to it, otherwise the window alone decides (a loaded plate never reads exactly zero)."""
+    est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
+    assert params.kinetic_dataset, "Cannot determine GRF on a dataset other than the kinetic dataset from Penny Hudson and Co."
+    if est.kinematic_model:
+        raise AssertionError("Dynamic model of the cheetah is required.")
+    data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, est.data_path)
+    fte = load_result_pickle(os.path.join(data_dir, "fte_kinetic", "fte.pickle"))
+    N = params.end_frame - params.start_frame
+    q_init = np.ascontiguousarray(fte["q"][:N], dtype=np.float64)
+    groups = skeleton.motor_groups()
+    nm = sum(len(cols) for _, cols in groups)
+    init_tau = np.zeros((N, nm))
+    for name, cols in groups:                                                       # {motor name: [N, components]} as save() and the reference write it
+        init_tau[:, cols] = np.asarray(fte["tau"][name], dtype=np.float64)[:N]
+    tau_box = bound_value(init_tau, 0.1)
+    with open(os.path.join(params.data_dir, "metadata.json"), "r", encoding="utf-8") as fh:
+        contact_json = json.load(fh)
+    table = os.path.join(params.data_dir, "grf", "data.csv")
+    if os.path.exists(table):
+        gz, _ = grf_profile(load_force_table(table), contact_json, N)
+        stance = (gz != 0).astype(np.int32)
+    else:
+        stance = np.zeros((N, len(skeleton.FEET)), np.int32)
+        for k, foot in enumerate(skeleton.FEET):
+            rec = contact_json["contacts"].get(f"{foot}_foot")
+            if rec:
+                a, b = int(rec[0][0]) - contact_json["start_frame"], int(rec[0][1]) - contact_json["start_frame"]
+                stance[max(a, 0):max(min(b + 1, N - 1), 0), k] = 1                   # first window only, frames 0 .. N-2 (acinoset_misc.py:954, :1003)
+    opts = options if options is not None else abi.default_options(scene.fps)
+    opts.h = 1.0 / scene.fps
+    if options is None:
+        opts.tol_cost, opts.max_iter = 1e-7, 600
+    ko = kinetic_options if kinetic_options is not None else abi.default_kinetic_options(skeleton.dyn_options(est.name), scene.fps, True)
+    if kinetic_options is None:
+        ko.foot_height_tol = 0.03                                                    # foot_height in [-0.03, 0.03] during a contact (:1010-1012)
+        ko.slip_max = 0.0                                                            # this NLP has no no-slip rule (estimate_kinetics adds it to ITS model)
+    if est.bound_eom_error is not None:
+        ko.slack_bound = float(max(abs(est.bound_eom_error[0]), abs(est.bound_eom_error[1])))
+    skk = skeleton.without_motion_model(sk)
+    h = _lib.Handle(skk, est.cams, opts, None, device=est.device)
+    try:
+        t0 = time()
+        res = h.solve_kinetic_host(ko, q_init[None], est.meas[None], est.weight[None], stance[None], tau_box=tau_box[None])
+        est.opt_time_s = time() - t0
+        import torch
+        dev = torch.device("cuda", est.device)
+        qd = torch.tensor(res["q"], device=dev)
+        pos = torch.empty((1, N, 24, 3), dtype=torch.float64, device=dev); com = torch.empty((1, N, 3), dtype=torch.float64, device=dev)
+        h.forward_kinematics(qd, pos, com); h.synchronize()
+        est.com_pos = com[0].cpu().numpy()
+        est.com_vel = (est.com_pos[1:] - est.com_pos[:-1]) * scene.fps
+    finally:
+        h.close()
+    st, ks = res["stats"][0], res["kstats"][0]
+    est.result = res
+    est.kinetic = dict(tau=res["tau"][0], lam=res["lam"][0], grf=res["grf"][0], slack=res["slack"][0], stance=stance, ground_height=ko.ground_height,
+                       tau_box=tau_box)
+    est.costs = {"measurement": st.cost_meas, "energy": ks.cost_energy, "eom_error": ks.cost_eom, "torque": ks.cost_torque}
+    base_err = float(np.sqrt(np.mean((q_init[:, :6] - res["q"][0][:, :6]) ** 2)))
+    rel_err = float(np.sqrt(np.mean((q_init[:, 6:] - res["q"][0][:, 6:]) ** 2)))
+    if solver_output:
+        print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- energy: {ks.cost_energy}\n-- eom_error: {ks.cost_eom}\n-- torque: {ks.cost_torque}\n"
+              f"status {st.status}, {st.iterations} LM iterations, {st.outer} multiplier updates, {est.opt_time_s:.3f} s\n"
+              f"max |slack_eom| {ks.max_slack:.3e} (bound {ko.slack_bound}), max violated inequality {ks.max_violation:.3e}\n"
+              f"RMSE base: {base_err:.4f}\nRMSE links: {rel_err:.4f}")
+    ok = st.status == abi.OK and ks.max_slack <= ko.slack_bound
+    if ok:
+        est.save("fte_grf", fname="fte", out_dir_prefix=out_dir_prefix)              # acinoset_opt.py:1045-1046
+    return ok

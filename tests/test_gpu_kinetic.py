@@ -183,6 +183,31 @@ def test_estimate_kinetics_end_to_end_from_files(tmp_path, gpu_handle_factory):
     assert np.abs(r2["grf"][0][:, :, 0] - gz).max() < 1e-12 or np.abs(r2["grf"][0][2:, :, 0] - gz[2:]).max() < 1e-12   # reported as prescribed (nodes 0, 1 carry no dynamics)
     assert np.sqrt(((r2["positions"][0] - truth) ** 2).sum(-1).mean()) < 0.03
     assert set(est2.synthesised_grf) == {f"{f}_foot" for f in skeleton.FEET}
+    # ---- last stage of the kinetic-dataset pipeline (run_dataset.py:1125-1138): the module-level estimate_grf solves again from fte_kinetic/fte.pickle
+    # with every torque within 10 % of its stored value and the forces free inside the measured contact windows (here: metadata.json's)
+    import dataclasses
+    with pytest.raises(AssertionError):
+        E.estimate_grf(est2, solver_output=False)                                    # "Cannot determine GRF on a dataset other than the kinetic dataset"
+    est3 = E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, solver_path="/unused/ipopt", enable_eom_slack=True,
+                             bound_eom_error=(-2.0, 2.0), include_camera_constraints=True, kinematic_model=False)
+    est3.params = dataclasses.replace(est3.params, kinetic_dataset=True)             # (the synthetic files are AcinoSet-style; only the flag is the kinetic set's)
+    ok3 = E.estimate_grf(est3, solver_output=False)
+    r3 = est3.result
+    assert r3["stats"][0].status in (abi.OK, abi.MAX_ITER) and isinstance(ok3, bool)
+    stored = np.zeros((48, 22))
+    for name, cols in skeleton.motor_groups():
+        stored[:, cols] = d["tau"][name]
+    box = E.bound_value(stored, 0.1)
+    t3 = r3["tau"][0]
+    assert (t3[2:] >= box[2:, :, 0] - 1e-3).all() and (t3[2:] <= box[2:, :, 1] + 1e-3).all()
+    first_window = est3.kinetic["stance"]
+    assert first_window.sum() > 10 and np.all(first_window <= st) and np.all(first_window[47] == 0)        # first window of every foot, frames 0 .. N-2
+    assert np.all(r3["grf"][0][first_window == 0] == 0.0)
+    assert np.sqrt(((r3["positions"][0] - truth) ** 2).sum(-1).mean()) < 0.03
+    assert set(est3.costs) == {"measurement", "energy", "eom_error", "torque"}       # acinoset_opt.py:1027
+    if ok3:
+        g3 = E.load_result_pickle(os.path.join(str(tmp_path), info["data_path"], "fte_grf", "fte.pickle"))
+        assert g3["q"].shape == (48, 54) and len(g3["tau"]) == 16
 
 
 def test_gpu_kinematics_reproduce_the_reference_stored_contact_json(gpu_handle_factory):
