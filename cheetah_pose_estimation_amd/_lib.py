@@ -87,6 +87,7 @@ def load():
     lib.cpe_default_kinetic_options.restype = None
     lib.cpe_solve_kinetic.argtypes = [vp, C.POINTER(abi.KineticOptions), C.c_int32, C.c_int32] + [vp] * 13 + [C.POINTER(abi.Stats), C.POINTER(abi.KineticStats)]
     lib.cpe_solve_kinetic_fixed.argtypes = [vp, C.POINTER(abi.KineticOptions), C.c_int32, C.c_int32] + [vp] * 14 + [C.POINTER(abi.Stats), C.POINTER(abi.KineticStats)]
+    lib.cpe_solve_kinetic_force_box.argtypes = [vp, C.POINTER(abi.KineticOptions), C.c_int32, C.c_int32] + [vp] * 14 + [C.POINTER(abi.Stats), C.POINTER(abi.KineticStats)]
     lib.cpe_solve_kinetic_bounded.argtypes = [vp, C.POINTER(abi.KineticOptions), C.c_int32, C.c_int32] + [vp] * 14 + [C.POINTER(abi.Stats), C.POINTER(abi.KineticStats)]
     lib.cpe_eval_kinetic_nodes.argtypes = [vp, C.POINTER(abi.KineticOptions), C.c_int32, C.c_int32] + [vp] * 11
     _LIB = lib
@@ -353,16 +354,16 @@ class Handle:
         return gz.cpu().numpy(), gxy.cpu().numpy(), res.cpu().numpy()
 
     # ---- physics-based trajectory model (config 4) -------------------------------------------------------
-    def solve_kinetic(self, kopts, q_init, meas, weight, stance, q, dq, ddq, positions, meas_err, tau=None, lam=None, grf=None, slack=None, grf_fixed=None, tau_box=None):
-        """device tensors (stance int32 [B, N, n_feet]; grf_fixed [B, N, n_feet, 3] = prescribed net foot forces, or None; tau_box [B, N, n_motors, 2] =
-        (lower, upper) bound of every torque, or None -- not both); returns (status, [Stats], [KineticStats])"""
+    def solve_kinetic(self, kopts, q_init, meas, weight, stance, q, dq, ddq, positions, meas_err, tau=None, lam=None, grf=None, slack=None, grf_fixed=None, tau_box=None, grf_box=None):
+        """device tensors (stance int32 [B, N, n_feet]; at most one of: grf_fixed [B, N, n_feet, 3] = prescribed net foot forces, tau_box [B, N, n_motors, 2] =
+        (lower, upper) bound of every torque, grf_box [B, N, n_feet, 3, 2] = (lower, upper) of the net (z, x, y) foot forces); returns (status, [Stats], [KineticStats])"""
         B, N = q_init.shape[0], q_init.shape[1]
         stats = (abi.Stats * max(B, 1))(); ks = (abi.KineticStats * max(B, 1))()
-        if grf_fixed is not None and tau_box is not None:
-            raise ValueError("prescribed foot forces and torque boxes are separate entry points")
-        fn = self.lib.cpe_solve_kinetic_bounded if tau_box is not None else self.lib.cpe_solve_kinetic_fixed
+        if sum(a is not None for a in (grf_fixed, tau_box, grf_box)) > 1:
+            raise ValueError("prescribed foot forces, torque boxes and force boxes are separate entry points")
+        fn = self.lib.cpe_solve_kinetic_bounded if tau_box is not None else (self.lib.cpe_solve_kinetic_force_box if grf_box is not None else self.lib.cpe_solve_kinetic_fixed)
         self._enter()
-        st = fn(self._h, C.byref(kopts), B, N, _ptr(q_init), _ptr(meas), _ptr(weight), _ptr(stance), _ptr(tau_box if tau_box is not None else grf_fixed), _ptr(q), _ptr(dq), _ptr(ddq),
+        st = fn(self._h, C.byref(kopts), B, N, _ptr(q_init), _ptr(meas), _ptr(weight), _ptr(stance), _ptr(tau_box if tau_box is not None else (grf_box if grf_box is not None else grf_fixed)), _ptr(q), _ptr(dq), _ptr(ddq),
                 _ptr(positions), _ptr(meas_err), _ptr(tau), _ptr(lam), _ptr(grf), _ptr(slack), stats, ks)
         self._leave()
         _check(st, "cpe_solve_kinetic", allow=(abi.OK, abi.MAX_ITER, abi.NUMERICAL))
@@ -371,7 +372,7 @@ class Handle:
     def n_constraint_rows(self):
         return sum(2 if self.sk.joint_kind[j] == abi.JOINT_REVOLUTE_Y else 1 for j in range(self.sk.n_joints))
 
-    def solve_kinetic_host(self, kopts, q_init, meas, weight, stance, grf_fixed=None, tau_box=None):
+    def solve_kinetic_host(self, kopts, q_init, meas, weight, stance, grf_fixed=None, tau_box=None, grf_box=None):
         """numpy in, numpy out (staged through HBM with torch)"""
         import torch
         dev = torch.device("cuda", self.device)
@@ -379,13 +380,14 @@ class Handle:
         qi, me, we, stn = T(q_init), T(meas), T(weight), T(stance, np.int32)
         gfx = None if grf_fixed is None else T(grf_fixed)
         tbx = None if tau_box is None else T(tau_box)
+        gbx = None if grf_box is None else T(grf_box)
         B, N = qi.shape[0], qi.shape[1]
         E = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
         nm, nf, nc = kopts.dyn.n_motors, kopts.dyn.n_feet, self.n_constraint_rows()
         q, dq, ddq = E(B, N, self.nq), E(B, N, self.nq), E(B, N, self.nq)
         pos, err = E(B, N, self.L, 3), E(B, N, self.n_cams, self.L, 2)
         tau, lam, grf, slack = E(B, N, nm), E(B, N, nc), E(B, N, nf, 5), E(B, N, self.nq)
-        st, stats, ks = self.solve_kinetic(kopts, qi, me, we, stn, q, dq, ddq, pos, err, tau, lam, grf, slack, grf_fixed=gfx, tau_box=tbx)
+        st, stats, ks = self.solve_kinetic(kopts, qi, me, we, stn, q, dq, ddq, pos, err, tau, lam, grf, slack, grf_fixed=gfx, tau_box=tbx, grf_box=gbx)
         self.synchronize()
         c = lambda t: t.cpu().numpy()
         return dict(status=st, q=c(q), dq=c(dq), ddq=c(ddq), positions=c(pos), meas_err=c(err), tau=c(tau), lam=c(lam), grf=c(grf), slack=c(slack),

@@ -1056,7 +1056,7 @@ void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kin
     o->inner_iterations = 30; o->_pad = 0;
 }
 
-static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const double* grf_fix = nullptr, const double* tau_box = nullptr) {
+static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const double* grf_fix = nullptr, const double* tau_box = nullptr, const double* grf_box = nullptr) {
     const DevModel& m = h->hm;
     DevKin& K = h->hk;
     memset(&K, 0, sizeof(K));
@@ -1083,6 +1083,7 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
     K.Mg = mt * d.eom.gravity; K.h = h->opts.h; K.ih = 1.0 / h->opts.h;
     for (int i = 0; i < m.nl; i++) { uint32_t mask = 0; for (int j = 0; j < m.nl; j++) { int a = j; while (a >= 0 && a != i) a = m.parent[a]; if (a == i) mask |= 1u << j; } K.sub_mask[i] = mask; }
     K.grf_fix = grf_fix;
+    K.grf_box = grf_box;
     K.tau_box = tau_box; K.mu_tau = h->kmut;            // (the workspace is sized before this is called)
     if (!h->dk) HIPCHK(hipMalloc(&h->dk, sizeof(DevKin)));
     HIPCHK(hipMemcpyAsync(h->dk, &K, sizeof(DevKin), hipMemcpyHostToDevice, h->stream));
@@ -1139,24 +1140,31 @@ cpe_status cpe_solve_kinetic(cpe_handle* h, const cpe_kinetic_options* opt, int3
 }
 
 static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
-                                     const double* weight, const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq,
+                                     const double* weight, const int32_t* stance, const double* grf_fixed, const double* tau_box, const double* grf_box, double* q, double* dq, double* ddq,
                                      double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                                      cpe_kinetic_stats* kstats);
 cpe_status cpe_solve_kinetic_fixed(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
                                    const double* weight, const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq,
                                    double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                                    cpe_kinetic_stats* kstats) {
-    return solve_kinetic_impl(h, opt, B, N, q_init, meas, weight, stance, grf_fixed, nullptr, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
+    return solve_kinetic_impl(h, opt, B, N, q_init, meas, weight, stance, grf_fixed, nullptr, nullptr, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
+}
+cpe_status cpe_solve_kinetic_force_box(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                       const double* weight, const int32_t* stance, const double* grf_box, double* q, double* dq, double* ddq,
+                                       double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                       cpe_kinetic_stats* kstats) {
+    if (!grf_box) return fail(CPE_BAD_ARG, "null argument");
+    return solve_kinetic_impl(h, opt, B, N, q_init, meas, weight, stance, nullptr, nullptr, grf_box, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
 }
 cpe_status cpe_solve_kinetic_bounded(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
                                      const double* weight, const int32_t* stance, const double* tau_box, double* q, double* dq, double* ddq,
                                      double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                                      cpe_kinetic_stats* kstats) {
     if (!tau_box) return fail(CPE_BAD_ARG, "null argument");
-    return solve_kinetic_impl(h, opt, B, N, q_init, meas, weight, stance, nullptr, tau_box, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
+    return solve_kinetic_impl(h, opt, B, N, q_init, meas, weight, stance, nullptr, tau_box, nullptr, q, dq, ddq, positions, meas_err, tau, lambda, grf, slack, stats, kstats);
 }
 static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
-                                     const double* weight, const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq,
+                                     const double* weight, const int32_t* stance, const double* grf_fixed, const double* tau_box, const double* grf_box, double* q, double* dq, double* ddq,
                                      double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                                      cpe_kinetic_stats* kstats) {
     if (!h || !opt || !q_init || !meas || !weight || !stance || !q) return fail(CPE_BAD_ARG, "null argument");
@@ -1171,7 +1179,7 @@ static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* o
     if (s != CPE_OK) return s;
     s = ensure_kws(h, B, N);
     if (s != CPE_OK) return s;
-    s = build_kin(h, opt, grf_fixed, tau_box);
+    s = build_kin(h, opt, grf_fixed, tau_box, grf_box);
     if (s != CPE_OK) return s;
     const DevModel& m = h->hm;
     const size_t Fw = F;

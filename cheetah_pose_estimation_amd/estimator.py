@@ -656,14 +656,14 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     `fix_grf=True`, run_dataset.py:1092-1140; acinoset_opt.py:813-866): the ground-reaction forces are PRESCRIBED -- the synthesised profile of
     `grf/data_synth.csv` (`synthesised_grf=True`) or the per-frame fit of `CheetahEstimator.estimate_grf` -- the feet are held near the ground
     (`ground_constraint`) and still (`no_slip`) while their force is positive, and torques, constraint forces and the trajectory are estimated
-    (cpe_solve_kinetic_fixed).  The whole NLP runs on the GPU.  `init_torques` has no effect here: the torques are minimised out exactly at
-    every evaluation, so they need no starting value.  `fix_grf=False` (forces free within 20 % of the profile) is not built."""
+    (cpe_solve_kinetic_fixed).  With `fix_grf=False` the same profile only BOXES the forces (acinoset_opt.py:838-850: `GRFz` and every `GRFxy` side
+    within `bound_value(profile, 0.2)`; cpe_solve_kinetic_force_box): net z in [0.8, 1.2] x profile, net x / y from the boxes of the two opposite
+    polygon sides (a side is non-negative), friction polyhedron kept; feet outside the profile's contact carry no force (the reference would let
+    them take up to 0.2 body weights: its box around zero).  The whole NLP runs on the GPU.  `init_torques` has no effect here: the torques are
+    minimised out exactly at every evaluation, so they need no starting value."""
     est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
     if est.kinematic_model:
         raise AssertionError("Dynamic model of the cheetah is required.")          # the reference asserts hasattr(model, 'eom_f')
-    if not joint_estimation and not fix_grf:
-        raise NotImplementedError("estimate_kinetics(joint_estimation=False, fix_grf=False): forces boxed to +-20 % of a profile are not built "
-                                  "(the node forces would need a box-constrained elimination)")
     if not use_2d_reprojections:
         raise NotImplementedError("the 3D kinematic cost (use_2d_reprojections=False) is not built")
     if params.enable_shutter_delay_estimation and scene.cam_idx is None:
@@ -685,6 +685,7 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     with open(os.path.join(data_dir, "grf", "autogen-contact.json") if auto else os.path.join(params.data_dir, "metadata.json"), "r", encoding="utf-8") as fh:
         contact_json = json.load(fh)
     grf_fixed = None
+    grf_box = None
     if joint_estimation:
         stance = stance_from_contacts(contact_json, N, params.start_frame)
     else:
@@ -703,6 +704,14 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
         est.synthesised_grf = {f"{foot}_foot": [float(v) for v in gz[:, k]] for k, foot in enumerate(skeleton.FEET)}
         stance = (gz > 0).astype(np.int32)                                           # height / no-slip rules where a force acts (:832-835, :853-864)
         grf_fixed = np.ascontiguousarray(np.stack([gz, gxy[..., 0] - gxy[..., 2], gxy[..., 1] - gxy[..., 3]], axis=-1))
+        if not fix_grf:
+            bz = bound_value(gz, 0.2)                                                  # [N, 4, 2]
+            bs = np.maximum(bound_value(gxy, 0.2), 0.0)                                # [N, 4, 4 sides, 2]; a polygon side is >= 0
+            grf_box = np.zeros((N, 4, 3, 2))
+            grf_box[:, :, 0] = bz
+            grf_box[:, :, 1, 0] = bs[:, :, 0, 0] - bs[:, :, 2, 1]; grf_box[:, :, 1, 1] = bs[:, :, 0, 1] - bs[:, :, 2, 0]      # x = (+x side) - (-x side)
+            grf_box[:, :, 2, 0] = bs[:, :, 1, 0] - bs[:, :, 3, 1]; grf_box[:, :, 2, 1] = bs[:, :, 1, 1] - bs[:, :, 3, 0]
+            grf_fixed = None
     pri = None
     if not disable_pose_prior and scene.cam_idx is not None:                         # acinoset_opt.py:916-917
         from . import priors as _priors
@@ -725,7 +734,7 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     try:
         t0 = time()
         res = h.solve_kinetic_host(ko, q_init[None], est.meas[None], est.weight[None], stance[None],
-                                   grf_fixed=None if grf_fixed is None else grf_fixed[None])
+                                   grf_fixed=None if grf_fixed is None else grf_fixed[None], grf_box=None if grf_box is None else grf_box[None])
         est.opt_time_s = time() - t0
         import torch
         dev = torch.device("cuda", est.device)

@@ -394,6 +394,15 @@ cpe_status cpe_solve_kinetic_bounded(cpe_handle* h, const cpe_kinetic_options* o
                                      double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
                                      cpe_kinetic_stats* kstats);
 
+/* the same with the net force of every stance foot BOXED (estimate_kinetics(joint_estimation=False, fix_grf=False), acinoset_opt.py:838-850: `GRFz` and
+ * the `GRFxy` sides unfixed within `bound_value(profile, 0.2)`): grf_box [B][N][n_feet][3][2] = (lower, upper) of the net (z, x, y) force in body
+ * weights, device pointer, read where stance != 0.  The boxes replace the constants of the positivity / force_max rows of the foot; the friction
+ * polyhedron stays, as in the reference (it removes that constraint only when the forces are fixed). */
+cpe_status cpe_solve_kinetic_force_box(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q_init, const double* meas,
+                                       const double* weight, const int32_t* stance, const double* grf_box, double* q, double* dq, double* ddq,
+                                       double* positions, double* meas_err, double* tau, double* lambda, double* grf, double* slack, cpe_stats* stats,
+                                       cpe_kinetic_stats* kstats);
+
 /* diagnostic building block of cpe_solve_kinetic (as cpe_eval_normal is of cpe_solve): ONE evaluation of the physics terms of every node at
  * Euler q, multipliers zero, forces from a cold start -- what ASL hands IPOPT per node for the constraints of make_pyomo_model(include_eom_slack=True)
  * (acinoset_opt.py:510-514) after the node forces are minimised out.  Device pointers, each may be NULL: f [B][N][64] node forces (tau | lambda |

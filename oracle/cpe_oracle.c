@@ -1198,13 +1198,21 @@ cpe_status cpo_solve_kinetic(const cpe_skeleton* s, const cpe_camera* cams, int 
 /* with prescribed net foot forces grf_fixed [N][nf][3] (include/cpe.h, cpe_solve_kinetic_fixed), or NULL */
 static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
                                    const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
-                                   const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   const int32_t* stance, const double* grf_fixed, const double* tau_box, const double* grf_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
                                    double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst);
 cpe_status cpo_solve_kinetic_fixed(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
                                    const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
                                    const int32_t* stance, const double* grf_fixed, double* q, double* dq, double* ddq, double* positions, double* meas_err,
                                    double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
-    return solve_kinetic_impl(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, grf_fixed, NULL, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
+    return solve_kinetic_impl(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, grf_fixed, NULL, NULL, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
+}
+/* with the net force of every stance foot boxed: grf_box [N][nf][3][2] = (lower, upper) of (z, x, y) (include/cpe.h, cpe_solve_kinetic_force_box:
+ * estimate_kinetics(joint_estimation=False, fix_grf=False), acinoset_opt.py:838-850, lets the forces move within 20 % of a profile) */
+cpe_status cpo_solve_kinetic_force_box(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
+                                   const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
+                                   const int32_t* stance, const double* grf_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
+    return solve_kinetic_impl(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, NULL, NULL, grf_box, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
 }
 /* with every torque boxed: tau_box [N][n_motors][2] = (lower, upper) (include/cpe.h, cpe_solve_kinetic_bounded: the reference's module-level
  * estimate_grf, acinoset_opt.py:966-1048, bounds the torques to +-10 % of a previous solve) */
@@ -1212,11 +1220,11 @@ cpe_status cpo_solve_kinetic_bounded(const cpe_skeleton* s, const cpe_camera* ca
                                    const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
                                    const int32_t* stance, const double* tau_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
                                    double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
-    return solve_kinetic_impl(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, NULL, tau_box, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
+    return solve_kinetic_impl(s, cams, C, o, pr, ko, N, q_init, meas, weight, stance, NULL, tau_box, NULL, q, dq, ddq, positions, meas_err, tau, lam, grf, slack, st, kst);
 }
 static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_priors* pr,
                                    const cpe_kinetic_options* ko, int N, const double* q_init, const double* meas, const double* weight,
-                                   const int32_t* stance, const double* grf_fixed, const double* tau_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
+                                   const int32_t* stance, const double* grf_fixed, const double* tau_box, const double* grf_box, double* q, double* dq, double* ddq, double* positions, double* meas_err,
                                    double* tau, double* lam, double* grf, double* slack, cpe_stats* st, cpe_kinetic_stats* kst) {
     int nq = NQ(s);
     for (int p = 0; p < nq; p++) if (s->motion_w[p] != 0.0) return CPE_BAD_ARG;      /* the physics replaces the constant-acceleration cost */
@@ -1229,7 +1237,7 @@ static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* ca
     K.Mg = M * ko->dyn.eom.gravity;
     K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
     K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
-    K.tau_box = tau_box; K.mu_tau = (double*)calloc((size_t)N * K.nm * 2 + 1, sizeof(double));
+    K.grf_box = grf_box; K.tau_box = tau_box; K.mu_tau = (double*)calloc((size_t)N * K.nm * 2 + 1, sizeof(double));
     K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
     K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
     cpe_status rc = solve_impl(s, cams, C, o, pr, N, q_init, meas, weight, q, dq, ddq, positions, meas_err, st, &K);

@@ -96,13 +96,14 @@ def solve_batch(sk, cams, opts, q_init, meas, weight, threads=0, priors=None):
     return int(used), q, its
 
 
-def solve_kinetic(sk, cams, opts, priors, kopts, q_init, meas, weight, stance, grf_fixed=None, tau_box=None):
+def solve_kinetic(sk, cams, opts, priors, kopts, q_init, meas, weight, stance, grf_fixed=None, tau_box=None, grf_box=None):
     """physics-based trajectory model (cpo_solve_kinetic[_fixed | _bounded]): one sequence, numpy in / out; grf_fixed [N, nf, 3] = prescribed net
-    foot forces; tau_box [N, n_motors, 2] = (lower, upper) bound of every torque"""
+    foot forces; tau_box [N, n_motors, 2] = (lower, upper) bound of every torque; grf_box [N, nf, 3, 2] = (lower, upper) of the net (z, x, y) force"""
     q_init, meas, weight = _c(q_init), _c(meas), _c(weight)
     gf = None if grf_fixed is None else _c(grf_fixed)
     tb = None if tau_box is None else _c(tau_box)
-    assert gf is None or tb is None
+    gb = None if grf_box is None else _c(grf_box)
+    assert sum(a is not None for a in (gf, tb, gb)) <= 1
     stance = np.ascontiguousarray(stance, dtype=np.int32)
     N, Cn, L = weight.shape
     nq, nm, nf = sk.nq, kopts.dyn.n_motors, kopts.dyn.n_feet
@@ -111,9 +112,9 @@ def solve_kinetic(sk, cams, opts, priors, kopts, q_init, meas, weight, stance, g
     pos = np.empty((N, L, 3)); me = np.empty((N, Cn, L, 2))
     tau = np.empty((N, nm)); lam = np.empty((N, nc)); grf = np.empty((N, nf, 5)); slack = np.empty((N, nq))
     st = abi.Stats(); ks = abi.KineticStats()
-    fn = lib().cpo_solve_kinetic_bounded if tb is not None else lib().cpo_solve_kinetic_fixed
+    fn = lib().cpo_solve_kinetic_bounded if tb is not None else (lib().cpo_solve_kinetic_force_box if gb is not None else lib().cpo_solve_kinetic_fixed)
     rc = fn(C.byref(sk), cams, Cn, C.byref(opts), C.byref(priors) if priors is not None else None, C.byref(kopts), N,
-            _p(q_init), _p(meas), _p(weight), stance.ctypes.data_as(C.POINTER(C.c_int32)), _p(tb if tb is not None else gf), _p(q), _p(dq), _p(ddq), _p(pos), _p(me),
+            _p(q_init), _p(meas), _p(weight), stance.ctypes.data_as(C.POINTER(C.c_int32)), _p(tb if tb is not None else (gb if gb is not None else gf)), _p(q), _p(dq), _p(ddq), _p(pos), _p(me),
             _p(tau), _p(lam), _p(grf), _p(slack), C.byref(st), C.byref(ks))
     return dict(status=rc, q=q, dq=dq, ddq=ddq, positions=pos, meas_err=me, tau=tau, lam=lam, grf=grf, slack=slack, stats=st, kstats=ks)
 

@@ -199,3 +199,26 @@ def test_torque_boxes(oracle):
     big = np.abs(free["tau"][2:]) > 0.05                                                          # torques that the halved boxes exclude (the model's torques are O(0.1))
     assert big.any() and (np.abs(t[big]) < 0.56 * np.abs(free["tau"][2:][big])).all()
     assert held["kstats"].cost_eom > free["kstats"].cost_eom and held["stats"].cost > free["stats"].cost
+
+
+def test_force_boxes(oracle):
+    """cpo_solve_kinetic_force_box (estimate_kinetics(joint_estimation=False, fix_grf=False), acinoset_opt.py:838-850): boxes of +-20 % around the joint
+    estimate's own forces leave that estimate in place; boxes around 70 % of them hold the forces at the boxes' upper faces."""
+    sk, cams, opts, ko, d = _problem(12, n_cams=6, init_noise=0.02)
+    kin = oracle.solve(skeleton.build_skeleton("phantom", 24), cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
+    opts.tol_cost, opts.max_iter = 1e-9, 400
+    free = oracle.solve_kinetic(sk, cams, opts, None, ko, kin["q"], d["meas"][0], d["weight"][0], d["stance"][0])
+    g = free["grf"]
+    net = np.stack([g[..., 0], g[..., 1] - g[..., 3], g[..., 2] - g[..., 4]], axis=-1)
+    same = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"], d["meas"][0], d["weight"][0], d["stance"][0], grf_box=_bound_value(net, 0.2))
+    assert same["status"] == abi.OK and np.abs(same["grf"] - g).max() < 1e-3 * max(1.0, np.abs(g).max())
+    assert abs(same["stats"].cost - free["stats"].cost) < 1e-4 * free["stats"].cost
+    box = _bound_value(0.7 * net, 0.2)
+    held = oracle.solve_kinetic(sk, cams, opts, None, ko, free["q"], d["meas"][0], d["weight"][0], d["stance"][0], grf_box=box)
+    assert held["status"] in (abi.OK, abi.MAX_ITER)
+    on = d["stance"][0][2:] == 1
+    hz = held["grf"][2:, :, 0]
+    assert (hz[on] >= box[2:, :, 0, 0][on] - 1e-4).all() and (hz[on] <= box[2:, :, 0, 1][on] + 1e-4).all() and np.all(held["grf"][2:][~on] == 0.0)
+    big = on & (net[2:, :, 0] > 0.3)
+    assert big.any() and (hz[big] < 0.85 * net[2:, :, 0][big]).all()                   # 0.7 x 1.2 = 0.84 of the free force at most
+    assert held["kstats"].cost_eom > free["kstats"].cost_eom
