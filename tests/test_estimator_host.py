@@ -110,3 +110,16 @@ def test_pairwise_pseudo_measurements_follow_the_reference_rule(tmp_path):
     l = skeleton.MARKERS.index("r_front_paw")
     uv0, _ = synth.project_numpy(info["cams"][0], info["pos_true"][4:16, l])
     assert np.abs(m[:, 0, 0, l] - uv0).max() < 12.0
+
+
+def test_bound_value_is_the_reference_rule():
+    """acinoset_misc.bound_value (:84-90): a positive value v -> ((1 - s) v, (1 + s) v), a negative one -> ((1 + s) v, (1 - s) v), exactly zero ->
+    (-s, s).  estimate_grf (torques, s = 0.1) and estimate_kinetics(fix_grf=False) (forces, s = 0.2) build their boxes with it."""
+    from cheetah_pose_estimation_amd import estimator as E
+    b = E.bound_value([2.0, -4.0, 0.0, 1e-300], 0.1)
+    assert b.shape == (4, 2)
+    assert np.allclose(b[0], [1.8, 2.2]) and np.allclose(b[1], [-4.4, -3.6]) and np.allclose(b[2], [-0.1, 0.1])
+    assert b[3, 0] > 0 and b[3, 1] > b[3, 0]                                     # any non-zero value keeps its sign
+    assert (b[:, 0] < b[:, 1]).all()
+    m = E.bound_value(np.zeros((3, 2)), 0.2)
+    assert m.shape == (3, 2, 2) and np.all(m[..., 0] == -0.2) and np.all(m[..., 1] == 0.2)
