@@ -262,3 +262,36 @@ def test_contact_heuristic_on_a_second_stored_run(oracle):
             assert d[0] == d[1] and abs(int(d[0])) <= (1 if n == "HFR_foot" else 0), (n, contacts[n], Z["windows"][i])
             if shift == 0.02:                                                    # the below-threshold runs measure the ground offset itself: 2 cm lower matches the stored ones to a frame
                 assert np.abs(np.array(by_height[n][0][:2]) - Z["windows_height_only"][i]).max() <= 1, (n, by_height[n])
+
+
+@pytest.mark.parametrize("fixture,animal,n_frames,start,end,stance,windows,labels", [
+    ("contacts_pin_phantom2017.npz", "phantom", 44, 59, 103, 9, [[84, 92], [75, 83], [76, 84], [67, 75]], ["leading", "trailing", "leading", "trailing"]),
+    ("contacts_pin_jules2.npz", "jules", 34, 80, 114, 8, [[103, 110], [97, 104], [83, 90], [87, 94]], ["leading", "trailing", "trailing", "leading"]),
+])
+def test_contact_heuristic_on_stored_runs_with_cameras_from_another_sequence(oracle, fixture, animal, n_frames, start, end, stance, windows, labels):
+    """`2017_08_29/top/phantom/run1_1` (fte_kinematic_4) and `2017_08_29/top/jules/run1_2` (fte_kinematic_1), 90 fps: the cameras are NOT fitted to these
+    sequences -- they are the ones recovered from jules run1_1 of the same day and rig (tests/golden/fk_csv_pin_jules.npz) -- and this repository's
+    FK + link lengths of the animal + joint equalities still reproduce the reference's stored monocular 2D files cam{1..6}_fte.csv to 2.2e-5 px
+    (phantom) / 2.3e-4 px (jules run1_2) worst (fixture worst_px; tools/pin_contacts_from_csv.py <seq> <animal> fk_csv_pin_jules.npz <dir> <out>
+    stance 90): an FK / marker / projection pin with no camera freedom left.  On the recovered angles the contact heuristic gives the stored
+    `grf/autogen-contact.json` EXACTLY -- start and end frame, every window, every leading / trailing label, the stance length at the run's
+    speed -- unchanged by +-2 cm of ground offset."""
+    import os
+    from cheetah_pose_estimation_amd import skeleton
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    q, fps = Z["q"], float(Z["fps"])
+    assert fps == 90.0 and q.shape[0] == n_frames and int(Z["start_frame"]) == start and int(Z["end_frame"]) == end and float(Z["worst_px"]) < 1e-3
+    dq = np.zeros_like(q); dq[1:] = (q[1:] - q[:-1]) * fps; dq[0] = dq[1]
+    sk = skeleton.build_skeleton(animal, 24)
+    pos = oracle.markers(sk, q)
+    vel = np.array([np.einsum("ldp,p->ld", oracle.markers_jac(sk, q[n])[1], dq[n]) for n in range(q.shape[0])])
+    up, off = Z["ground_normal"], float(Z["ground_offset"])
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    names = [f"{f}_foot" for f in skeleton.FEET]
+    speed = float(np.linalg.norm(np.diff(pos.mean(1), axis=0) * fps, axis=1).mean())
+    assert ct.stance_frames(speed, fps) == stance
+    for shift in (-0.02, 0.0, 0.02):
+        contacts, _ = ct.contact_detection(pos[:, feet] @ up - off - shift, vel[:, feet] @ up, names, start, speed, fps)
+        assert [contacts[n][0][:2] for n in names] == windows == [list(map(int, w)) for w in Z["windows"]]
+        assert [contacts[n][0][3] for n in names] == labels == [str(l) for l in Z["labels"]]
+        assert all(len(contacts[n]) == 1 for n in names)

@@ -72,10 +72,11 @@ def main():
     q_out = np.zeros((N, sk.nq)); worst = 0.0
     x = None
     for n in range(N):
-        q0 = Z["q"][n] if x is None else q_out[n - 1]          # multi-view solution of the same frames / previous frame as the start
+        zq = Z["q"][min(n, len(Z["q"]) - 1)]                   # (the camera fixture may come from ANOTHER sequence of the same rig: any pose will do as a start)
+        q0 = zq if x is None else q_out[n - 1]                 # multi-view solution of the same frames / previous frame as the start
         x0 = np.concatenate([q0[trunk], alpha_of(q0)])
         best = None
-        for start in (x0, np.concatenate([Z["q"][n][trunk], alpha_of(Z["q"][n])])):
+        for start in (x0, np.concatenate([zq[trunk], alpha_of(zq)])):
             f = lambda xx: np.concatenate([(P.project(cams[c], synth.fk_numpy(sk, q_of(xx, q0[5])[None])[0][0]) - uv[n, c]).ravel() for c in range(6)])
             s = least_squares(f, start, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=4000)
             if best is None or np.abs(s.fun).max() < np.abs(best.fun).max():
