@@ -267,6 +267,12 @@ def test_contact_heuristic_on_a_second_stored_run(oracle):
 @pytest.mark.parametrize("fixture,animal,n_frames,start,end,stance,windows,labels", [
     ("contacts_pin_phantom2017.npz", "phantom", 44, 59, 103, 9, [[84, 92], [75, 83], [76, 84], [67, 75]], ["leading", "trailing", "leading", "trailing"]),
     ("contacts_pin_jules2.npz", "jules", 34, 80, 114, 8, [[103, 110], [97, 104], [83, 90], [87, 94]], ["leading", "trailing", "trailing", "leading"]),
+    # third rig (2017_09_02/top; cameras of tests/golden/fk_csv_pin_0902top.npz, recovered from the MULTI-view result of jules/run1): the monocular
+    # result of the same run (fte_kinematic_0, 2.7e-6 px) and the phantom run of that day (run1_2, fte_kinematic_1, 1.7e-5 px)
+    ("contacts_pin_0902_jules.npz", "jules", 30, 68, 98, 6, [[89, 94], [85, 90], [72, 77], [74, 79]], ["leading", "trailing", "trailing", "leading"]),
+    ("contacts_pin_0902_phantom.npz", "phantom", 45, 39, 84, 9, [[58, 66], [67, 75], [49, 57], [54, 62]], ["trailing", "leading", "trailing", "leading"]),
+    # fourth rig (2017_09_02/bottom/jules/run2; cameras of fk_csv_pin_0902bot.npz from its multi-view result, monocular result fte_kinematic_1 at 1.5e-5 px)
+    ("contacts_pin_0902bot.npz", "jules", 33, 91, 124, 8, [[112, 119], [108, 115], [96, 103], [97, 104]], ["leading", "trailing", "trailing", "leading"]),
 ])
 def test_contact_heuristic_on_stored_runs_with_cameras_from_another_sequence(oracle, fixture, animal, n_frames, start, end, stance, windows, labels):
     """`2017_08_29/top/phantom/run1_1` (fte_kinematic_4) and `2017_08_29/top/jules/run1_2` (fte_kinematic_1), 90 fps: the cameras are NOT fitted to these

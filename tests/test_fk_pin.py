@@ -94,6 +94,37 @@ def test_second_animal_and_recording_year(oracle):
     assert np.abs(gotp - ZJ["uv"][:, 0]).max() > 1.0
 
 
+def test_third_rig_with_pixels_outside_the_image(oracle):
+    """`2017_09_02/top/jules/run1/fte_kinematic` (third rig; `tools/pin_fk_from_csv.py 2017_09_02/top/jules/run1 fte_kinematic fk_csv_pin_0902top.npz`):
+    30 frames x 6 cameras x 24 markers, of which 20 (marker, frame) pairs of camera 5 are stored as NaN (the reference's writer leaves pixels
+    outside the image empty); every stored number is reproduced to < 1e-5 px."""
+    Z3 = np.load(os.path.join(os.path.dirname(__file__), "golden", "fk_csv_pin_0902top.npz"))
+    sk = skeleton.build_skeleton(str(Z3["animal"]), 24)
+    assert str(Z3["animal"]) == "jules" and Z3["uv"].shape == (30, 6, 24, 2)
+    missing = np.isnan(Z3["uv"]).any(-1)
+    assert missing.sum() == 20 and missing[:, 4].sum() == 20                       # all in camera 5
+    cams = _cams(Z3)
+    pos = oracle.markers(sk, Z3["q"])
+    got = np.array([[[oracle.project(cams[c], pos[n, l]) for l in range(24)] for c in range(6)] for n in range(30)])
+    err = np.abs(got - Z3["uv"])[~missing]
+    assert err.max() < 1e-5 and np.sqrt((err ** 2).mean()) < 1e-6
+    assert max(np.abs(oracle.constraints(sk, x)).max() for x in Z3["q"]) < 1e-12
+
+
+def test_fourth_rig(oracle):
+    """`2017_09_02/bottom/jules/run2/fte_kinematic` (`tools/pin_fk_from_csv.py 2017_09_02/bottom/jules/run2 fte_kinematic fk_csv_pin_0902bot.npz`):
+    33 frames x 6 cameras x 24 markers reproduced to 2.7e-5 px worst (rms 2.1e-6 px)."""
+    Z4 = np.load(os.path.join(os.path.dirname(__file__), "golden", "fk_csv_pin_0902bot.npz"))
+    sk = skeleton.build_skeleton(str(Z4["animal"]), 24)
+    assert str(Z4["animal"]) == "jules" and Z4["uv"].shape == (33, 6, 24, 2) and not np.isnan(Z4["uv"]).any()
+    cams = _cams(Z4)
+    pos = oracle.markers(sk, Z4["q"])
+    got = np.array([[[oracle.project(cams[c], pos[n, l]) for l in range(24)] for c in range(6)] for n in range(33)])
+    err = np.abs(got - Z4["uv"])
+    assert err.max() < 1e-4 and np.sqrt((err ** 2).mean()) < 1e-5
+    assert max(np.abs(oracle.constraints(sk, x)).max() for x in Z4["q"]) < 1e-12
+
+
 def test_numpy_host_fk_agrees_on_the_recovered_angles():
     sk = skeleton.build_skeleton(str(Z["animal"]), 24)
     cams = _cams()

@@ -77,7 +77,7 @@ def main():
         x0 = np.concatenate([q0[trunk], alpha_of(q0)])
         best = None
         for start in (x0, np.concatenate([zq[trunk], alpha_of(zq)])):
-            f = lambda xx: np.concatenate([(P.project(cams[c], synth.fk_numpy(sk, q_of(xx, q0[5])[None])[0][0]) - uv[n, c]).ravel() for c in range(6)])
+            f = lambda xx: np.concatenate([np.nan_to_num(P.project(cams[c], synth.fk_numpy(sk, q_of(xx, q0[5])[None])[0][0]) - uv[n, c]).ravel() for c in range(6)])     # (NaN = stored pixel outside the image)
             s = least_squares(f, start, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=4000)
             if best is None or np.abs(s.fun).max() < np.abs(best.fun).max():
                 best = s

@@ -133,9 +133,10 @@ def main():
     X *= s; t01 = t01 * s
     Rs, ts = [np.eye(3), R01], [np.zeros(3), t01]
     for c in range(2, C):
-        R, t = pnp_dlt(X, nrm[c]); Rs.append(R); ts.append(t)
+        ok = ~np.isnan(nrm[c]).any(1)
+        R, t = pnp_dlt(X[ok], nrm[c][ok]); Rs.append(R); ts.append(t)
     cams = np.array([np.concatenate([K0, D0, inv_rodrigues(Rs[c]), ts[c]]) for c in range(C)])
-    res0 = np.concatenate([(project(cams[c], X) - uv[:, c].reshape(-1, 2)).ravel() for c in range(C)])
+    res0 = np.concatenate([np.nan_to_num(project(cams[c], X) - uv[:, c].reshape(-1, 2)).ravel() for c in range(C)])     # (NaN = a stored pixel outside the image: no row)
     print(f"after SfM init: rms reprojection {np.sqrt(np.mean(res0**2)):.3f} px")
 
     # ---- 2. point-based bundle adjustment (camera 0 pose fixed = gauge; scale drifts freely, fixed afterwards)
@@ -148,7 +149,7 @@ def main():
 
     def fun_ba(p):
         cp, Xp = unpack(p)
-        return np.concatenate([(project(cp[c], Xp) - uv[:, c].reshape(-1, 2)).ravel() for c in range(C)])
+        return np.concatenate([np.nan_to_num(project(cp[c], Xp) - uv[:, c].reshape(-1, 2)).ravel() for c in range(C)])
 
     spars = lil_matrix((C * npts * 2, C * 14 + npts * 3), dtype=int)
     for c in range(C):
@@ -175,7 +176,7 @@ def main():
         R = rodrigues(cams[c, 8:11]); t = cams[c, 11:14]
         Rn = R @ Rw.T; tn = t + R @ o
         cams[c, 8:11] = inv_rodrigues(Rn); cams[c, 11:14] = tn
-    chk = np.concatenate([(project(cams[c], Xw) - uv[:, c].reshape(-1, 2)).ravel() for c in range(C)])
+    chk = np.concatenate([np.nan_to_num(project(cams[c], Xw) - uv[:, c].reshape(-1, 2)).ravel() for c in range(C)])
     print(f"after re-framing: rms {np.sqrt(np.mean(chk**2)):.3e} px")
     Xw = Xw.reshape(N, L, 3)
 
@@ -265,7 +266,7 @@ def main():
     def fun_joint(p):
         pos = synth.fk_numpy(sk, q_from_u(p[:nU]))[0]
         cp = p[nU:].reshape(C, 14)
-        return np.concatenate([(project(cp[c], pos) - uv[:, c]).ravel() for c in range(C)])
+        return np.concatenate([np.nan_to_num(project(cp[c], pos) - uv[:, c]).ravel() for c in range(C)])
 
     spj = lil_matrix((C * N * L * 2, nU + C * 14), dtype=int)
     for c in range(C):
