@@ -9,6 +9,7 @@ no (q, cameras) could reproduce the 16 416 stored values; the recovered ones do 
 import os
 
 import numpy as np
+import pytest
 
 from cheetah_pose_estimation_amd import abi, skeleton, synth
 
@@ -123,6 +124,31 @@ def test_fourth_rig(oracle):
     err = np.abs(got - Z4["uv"])
     assert err.max() < 1e-4 and np.sqrt((err ** 2).mean()) < 1e-5
     assert max(np.abs(oracle.constraints(sk, x)).max() for x in Z4["q"]) < 1e-12
+
+
+@pytest.mark.parametrize("fixture,animal,n_frames,missing_cams,tol", [
+    ("fk_csv_pin_0303.npz", "phantom", 42, (3, 4), 1e-4),        # 2019_03_03/phantom/run: a 4-camera scene (cameras 4, 5 have no stored files)
+    ("fk_csv_pin_1209.npz", "jules", 30, (5,), 5e-5),            # 2017_12_09/bottom/jules/flick2: 5 cameras
+    ("fk_csv_pin_0309.npz", "jules", 34, (), 5e-5),              # 2019_03_09/jules/flick1: camera 2 partly outside the image (88 empty pixels)
+])
+def test_remaining_stored_sequences(oracle, fixture, animal, n_frames, missing_cams, tol):
+    """the other three sequences of data/test_set (`tools/pin_fk_from_csv.py <seq> fte_kinematic <fixture>`): cameras without stored files count as
+    empty pixels, cameras that see part of the run outside the image keep their stored NaNs; every stored number is reproduced to `tol` pixels.
+    With these, the FK / marker / joint / projection model is pinned on a stored result of EVERY sequence the reference ships (10 sequences, 7
+    recording days / rigs, both animals, 90 and 120 fps): 7 multi-view results with self-calibrated cameras (this file), the other 3 through
+    their monocular results with the cameras of a sibling sequence (tests/test_contacts.py)."""
+    Zs = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    sk = skeleton.build_skeleton(str(Zs["animal"]), 24)
+    assert str(Zs["animal"]) == animal and Zs["uv"].shape == (n_frames, 6, 24, 2)
+    missing = np.isnan(Zs["uv"]).any(-1)
+    for c in range(6):
+        assert missing[:, c].all() == (c in missing_cams)
+    cams = _cams(Zs)
+    pos = oracle.markers(sk, Zs["q"])
+    got = np.array([[[oracle.project(cams[c], pos[n, l]) for l in range(24)] for c in range(6)] for n in range(n_frames)])
+    err = np.abs(got - Zs["uv"])[~missing]
+    assert err.size >= n_frames * 24 * 2 * 3 and err.max() < tol and np.sqrt((err ** 2).mean()) < 0.1 * tol
+    assert max(np.abs(oracle.constraints(sk, x)).max() for x in Zs["q"]) < 1e-12
 
 
 def test_numpy_host_fk_agrees_on_the_recovered_angles():

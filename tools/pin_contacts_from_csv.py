@@ -34,9 +34,13 @@ SRC = f"/root/reference/data/test_set/{SEQ}"
 def load_uv(sub):
     arrs = []
     for c in range(1, 7):
-        rows = np.genfromtxt(os.path.join(SRC, sub, f"cam{c}_fte.csv"), delimiter=",", skip_header=2)
+        f = os.path.join(SRC, sub, f"cam{c}_fte.csv")
+        if not os.path.exists(f):      # camera outside the stored result (4- and 5-camera scenes): empty pixels
+            arrs.append(None); continue
+        rows = np.genfromtxt(f, delimiter=",", skip_header=2)
         arrs.append(rows[:, 1:].reshape(len(rows), 24, 3)[:, :, :2])
-    return np.stack(arrs, 1), int(rows[0, 0])
+    shape = next(a for a in arrs if a is not None).shape
+    return np.stack([a if a is not None else np.full(shape, np.nan) for a in arrs], 1), int(rows[0, 0])
 
 
 def main():
@@ -70,6 +74,7 @@ def main():
         return al
 
     q_out = np.zeros((N, sk.nq)); worst = 0.0
+    errs = np.zeros(N)
     x = None
     for n in range(N):
         zq = Z["q"][min(n, len(Z["q"]) - 1)]                   # (the camera fixture may come from ANOTHER sequence of the same rig: any pose will do as a start)
@@ -84,8 +89,19 @@ def main():
             if np.abs(best.fun).max() < 1e-6:
                 break
         q_out[n] = q_of(best.x, q0[5]); x = best.x
-        worst = max(worst, float(np.abs(best.fun).max()))
-        print(f"frame {n}: max |pixel error| {np.abs(best.fun).max():.3e}", flush=True)
+        errs[n] = float(np.abs(best.fun).max())
+        print(f"frame {n}: max |pixel error| {errs[n]:.3e}", flush=True)
+    # frames the forward sweep left in a local minimum (a monocular result can start far from the multi-view one): once more, backwards, from the
+    # recovered pose of the following frame
+    for n in range(N - 2, -1, -1):
+        if errs[n] > 1e-3 and errs[n + 1] <= 1e-3:
+            qn = q_out[n + 1]
+            f = lambda xx: np.concatenate([np.nan_to_num(P.project(cams[c], synth.fk_numpy(sk, q_of(xx, qn[5])[None])[0][0]) - uv[n, c]).ravel() for c in range(6)])
+            s2 = least_squares(f, np.concatenate([qn[trunk], alpha_of(qn)]), method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=4000)
+            if np.abs(s2.fun).max() < errs[n]:
+                q_out[n] = q_of(s2.x, qn[5]); errs[n] = float(np.abs(s2.fun).max())
+                print(f"frame {n} (backward): max |pixel error| {errs[n]:.3e}", flush=True)
+    worst = float(errs.max())
     print("worst pixel error", worst)
     # z-up frame: up = normal of the plane through the lowest positions of the four paws, offset so that those lie at z = 0
     pos = synth.fk_numpy(sk, q_out)[0]

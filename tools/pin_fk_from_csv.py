@@ -74,9 +74,13 @@ def project(cp, X):
 def load_uv():
     arrs = []
     for c in range(1, 7):
-        rows = np.genfromtxt(os.path.join(SRC, f"cam{c}_fte.csv"), delimiter=",", skip_header=2)
+        f = os.path.join(SRC, f"cam{c}_fte.csv")
+        if not os.path.exists(f):      # a camera the stored result does not cover (4- and 5-camera scenes): all its pixels count as empty
+            arrs.append(None); continue
+        rows = np.genfromtxt(f, delimiter=",", skip_header=2)
         arrs.append(rows[:, 1:].reshape(len(rows), 24, 3)[:, :, :2])
-    return np.stack(arrs, 1)          # [N, C, L, 2]
+    shape = next(a for a in arrs if a is not None).shape
+    return np.stack([a if a is not None else np.full(shape, np.nan) for a in arrs], 1)          # [N, C, L, 2]
 
 
 def essential_8pt(n1, n2):
@@ -125,15 +129,21 @@ def main():
     Kmat = np.array([[K0[0], 0, K0[2]], [0, K0[1], K0[3]], [0, 0, 1.0]])
     nrm = [_undistort_fisheye(uv[:, c].reshape(-1, 2), Kmat, D0) for c in range(C)]
     # ---- 1. two-view geometry + scale + PnP
-    R01, t01 = essential_8pt(nrm[0], nrm[1])
-    X = _triangulate(nrm[0], nrm[1], np.eye(3), np.zeros(3), R01, t01)
+    assert not np.isnan(nrm[0]).any(), "camera 1 is the gauge of the bundle adjustment: it must see every stored point"
+    j2 = next(c for c in range(1, C) if not np.isnan(nrm[c]).any())          # second view of the two-view start: the first other camera without empty pixels
+    R01, t01 = essential_8pt(nrm[0], nrm[j2])
+    X = _triangulate(nrm[0], nrm[j2], np.eye(3), np.zeros(3), R01, t01)
     Xf = X.reshape(N, L, 3)
     L_base = 2.0 * abs(sk.marker_off[5][0])
     s = L_base / np.median(np.linalg.norm(Xf[:, 5] - Xf[:, 4], axis=1))
     X *= s; t01 = t01 * s
-    Rs, ts = [np.eye(3), R01], [np.zeros(3), t01]
-    for c in range(2, C):
+    Rs, ts = [np.eye(3)], [np.zeros(3)]
+    for c in range(1, C):
+        if c == j2:
+            Rs.append(R01); ts.append(t01); continue
         ok = ~np.isnan(nrm[c]).any(1)
+        if ok.sum() < 12:              # camera without stored pixels: a placeholder that no residual touches
+            Rs.append(np.eye(3)); ts.append(np.array([0.0, 0.0, 5.0])); continue
         R, t = pnp_dlt(X[ok], nrm[c][ok]); Rs.append(R); ts.append(t)
     cams = np.array([np.concatenate([K0, D0, inv_rodrigues(Rs[c]), ts[c]]) for c in range(C)])
     res0 = np.concatenate([np.nan_to_num(project(cams[c], X) - uv[:, c].reshape(-1, 2)).ravel() for c in range(C)])     # (NaN = a stored pixel outside the image: no row)
