@@ -302,6 +302,16 @@ def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_
     hj = gpu_handle_factory(skj, _cams(ZJ))
     rj = hj.eval_resjac_host(ZJ["q"][None], np.ascontiguousarray(ZJ["uv"][None]), np.ones((1, 30, 6, 24)))[0]
     assert np.abs(rj).max() < 1e-5 and np.sqrt((rj ** 2).mean()) < 1e-6
+    # the other recorded days / rigs (tests/test_fk_pin.py): pixels the reference stored as empty (NaN: outside the image, or a camera the scene does
+    # not have) are fed as 0 and left out of the statement
+    for fx, tol in (("fk_csv_pin_0902top.npz", 1e-5), ("fk_csv_pin_0902bot.npz", 1e-4), ("fk_csv_pin_0303.npz", 1e-4), ("fk_csv_pin_1209.npz", 5e-5), ("fk_csv_pin_0309.npz", 5e-5)):
+        Zs = np.load(os.path.join(os.path.dirname(__file__), "golden", fx))
+        sks = skeleton.build_skeleton(str(Zs["animal"]), 24)
+        hs = gpu_handle_factory(sks, _cams(Zs))
+        n = Zs["q"].shape[0]
+        missing = np.isnan(Zs["uv"]).any(-1)
+        rs = hs.eval_resjac_host(Zs["q"][None], np.ascontiguousarray(np.nan_to_num(Zs["uv"])[None]), np.ones((1, n, 6, 24)))[0][0]
+        assert np.abs(rs[~missing]).max() < tol, (fx, np.abs(rs[~missing]).max())
 
 
 def test_solve_on_the_real_run_matches_oracle(oracle, gpu_handle_factory):
