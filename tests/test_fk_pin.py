@@ -160,12 +160,14 @@ def test_numpy_host_fk_agrees_on_the_recovered_angles():
         assert np.abs(uv - Z["uv"][:, c]).max() < 1e-4
 
 
-def real_run_problem(noise_px=2.0, drop=0.4, outliers=0.05, init_noise=0.05, seed=0):
+def real_run_problem(noise_px=2.0, drop=0.4, outliers=0.05, init_noise=0.05, seed=0, fixture=None):
     """An estimation problem on REAL cheetah motion: the 57-frame trajectory and the 6 cameras recovered from the
     reference's stored run, its own reprojections as measurements plus DLC-like noise, drop-outs and outliers, and
-    a perturbed start.  Limb links swing beyond the horizontal under a rolled trunk in this run."""
-    sk = skeleton.build_skeleton(str(Z["animal"]), 24)
-    q, uv = Z["q"], Z["uv"]
+    a perturbed start.  Limb links swing beyond the horizontal under a rolled trunk in this run.  `fixture`: another of the
+    recovered runs (file name in tests/golden; it must have no empty pixels)."""
+    Zr = Z if fixture is None else np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    sk = skeleton.build_skeleton(str(Zr["animal"]), 24)
+    q, uv = Zr["q"], Zr["uv"]
     N = q.shape[0]
     rng = np.random.default_rng(seed)
     meas = uv + rng.normal(0, noise_px, uv.shape)
@@ -176,7 +178,7 @@ def real_run_problem(noise_px=2.0, drop=0.4, outliers=0.05, init_noise=0.05, see
     ind = skeleton.independent_dofs(sk)
     q_init = q.copy()
     q_init[:, ind] += rng.normal(0, init_noise, (N, len(ind)))
-    return sk, _cams(), q_init, np.ascontiguousarray(meas), weight, q
+    return sk, _cams(Zr), q_init, np.ascontiguousarray(meas), weight, q
 
 
 def test_oracle_solver_on_the_real_run(oracle):

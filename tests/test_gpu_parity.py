@@ -331,6 +331,17 @@ def test_solve_on_the_real_run_matches_oracle(oracle, gpu_handle_factory):
     assert st.max_bound_violation < 1e-5
     err = np.sqrt(((out["positions"][0] - oracle.markers(sk, q_ref)) ** 2).sum(-1))
     assert np.sqrt((err ** 2).mean()) < 0.008
+    # a second real run: the other animal, 90 fps, another rig (2017_08_29/top/jules/run1_1, 30 frames): 35 iterations in both, positions to 1e-12 m
+    sk, cams, q_init, meas, weight, q_ref = real_run_problem(fixture="fk_csv_pin_jules.npz", seed=3)
+    h2 = gpu_handle_factory(sk, cams, opts)
+    out = h2.solve_host(q_init[None], meas[None], weight[None])
+    ref = oracle.solve(sk, cams, opts, None, q_init, meas, weight)
+    st = out["stats"][0]
+    assert st.status == ref["stats"].status == abi.OK and abs(st.iterations - ref["stats"].iterations) <= 2
+    assert np.sqrt(((out["positions"][0] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-6
+    assert abs(st.cost - ref["stats"].cost) < 1e-8 * abs(ref["stats"].cost)
+    err = np.sqrt(((out["positions"][0] - oracle.markers(sk, q_ref)) ** 2).sum(-1))
+    assert np.sqrt((err ** 2).mean()) < 0.012
 
 
 def test_frame_normal_matches_oracle(sk25, cams6, oracle, gpu_handle_factory):
