@@ -1,0 +1,52 @@
+"""A pin of the MASS model on the reference's own stored physics-based results (CPU; the GPU twin is in tests/test_gpu_kinetic.py).
+
+`fte_kinetic_<cam>/cam{1..6}_fte.csv` are the 2D reprojections of the trajectories the reference's physics-based monocular model found
+(estimate_kinetics, acinoset_opt.py:693-963, equations of motion from models/*-test_tmp.robot).  The joint angles are recovered from them
+with cameras that are already pinned (tools/pin_contacts_from_csv.py <seq> phantom <camera fixture> fte_kinetic_<cam> ...; 2.3e-6 px and
+7.6e-6 px worst); tests/golden/kinetic_pin_*.npz hold those angles and the stance table of the stored grf/autogen-contact.json.
+
+In the frames in which, by that table, no paw is on the ground, nothing but gravity acts on the animal: whatever the limbs do, the centre
+of mass of a correct mass model falls with g.  The reference's result obeys ITS mass model (masses and centre-of-mass offsets of
+cheetah_params.py inside its equations of motion); here the centre of mass is computed from THIS repository's link masses, centre-of-mass
+offsets, link lengths and forward kinematics -- the same tables the GRF fit and the physics-based model use -- and its second difference at
+the recording's frame rate is compared with 9.81 m/s^2.  A wrong mass table, a wrong frame rate or a wrong chain shows at once (control below)."""
+import os
+
+import numpy as np
+import pytest
+
+from cheetah_pose_estimation_amd import skeleton
+
+G = 9.81
+
+
+def _flight_acceleration(oracle, sk, Z):
+    q, fps, st = Z["q"], float(Z["fps"]), Z["stance"]
+    com = oracle.com(sk, q)
+    acc = (com[2:] - 2.0 * com[1:-1] + com[:-2]) * fps ** 2                      # at frames 1 .. N-2
+    fl = [n for n in range(1, len(q) - 1) if st[n - 1:n + 2].sum() == 0]           # no paw down in any of the three frames of the difference
+    return acc[[n - 1 for n in fl]], fl
+
+
+@pytest.mark.parametrize("fixture", ["kinetic_pin_phantom2017.npz", "kinetic_pin_phantom0902.npz"])
+def test_centre_of_mass_falls_with_g_in_the_flight_phases_of_the_stored_physics_results(oracle, fixture):
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    assert float(Z["worst_px"]) < 1e-4 and float(Z["fps"]) == 90.0
+    sk = skeleton.build_skeleton("phantom", 24)
+    A, fl = _flight_acceleration(oracle, sk, Z)
+    assert len(fl) == 14                                                          # two aerial phases in each run
+    mag = np.linalg.norm(A, axis=1)
+    mean = A.mean(0)
+    assert abs(np.linalg.norm(mean) - G) < 0.015 * G                               # 9.875 and 9.755 m/s^2: the mean is within 0.7 %
+    assert np.abs(mag - G).max() < 0.06 * G                                        # every single flight frame within 5 % (second differences at 90 fps)
+    down = -mean / np.linalg.norm(mean)
+    assert np.degrees(np.arccos(np.clip(down @ Z["ground_normal"], -1, 1))) < 5.0  # and it points along the normal of the plane the paws touch
+    # control: the same angles with the total mass spread evenly over the links -- no longer a body in free fall
+    sku = skeleton.build_skeleton("phantom", 24)
+    total = sum(sku.mass[i] for i in range(sku.n_links))
+    for i in range(sku.n_links):
+        sku.mass[i] = total / sku.n_links
+    Au, _ = _flight_acceleration(oracle, sku, Z)
+    assert np.abs(np.linalg.norm(Au, axis=1) - G).max() > 0.25 * G
+    # control: the wrong frame rate (120 instead of 90 fps) scales the acceleration by 16 / 9
+    assert abs(np.linalg.norm(mean) * (120.0 / 90.0) ** 2 - G) > 0.7 * G

@@ -317,3 +317,25 @@ def test_force_boxes_match_oracle(oracle, gpu_handle_factory):
         assert np.all(r["grf"][b][2:][~on] == 0.0)
         if ok:
             assert (gz[on] >= lo[b, 2:, :, 0][on] - 1e-4).all() and (gz[on] <= hi[b, 2:, :, 0][on] + 1e-4).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["kinetic_pin_phantom2017.npz", "kinetic_pin_phantom0902.npz"])
+def test_gpu_centre_of_mass_falls_with_g_on_the_stored_physics_results(oracle, gpu_handle_factory, fixture):
+    """GPU twin of tests/test_free_flight_pin.py: the centre of mass from cpe_forward_kinematics (k_fk: link masses, centre-of-mass offsets, chain) on
+    the joint angles of the reference's stored physics-based results falls with 9.81 m/s^2 in the frames without ground contact."""
+    import torch
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    sk = skeleton.build_skeleton("phantom", 24)
+    h = gpu_handle_factory(sk, synth.make_cameras(6))
+    q, fps, st = Z["q"], float(Z["fps"]), Z["stance"]
+    dev = torch.device("cuda", 0)
+    N = q.shape[0]
+    pos = torch.empty((1, N, 24, 3), dtype=torch.float64, device=dev); com = torch.empty((1, N, 3), dtype=torch.float64, device=dev)
+    h.forward_kinematics(torch.tensor(q[None], device=dev), pos, com); h.synchronize()
+    com = com[0].cpu().numpy()
+    assert np.abs(com - oracle.com(sk, q)).max() < 1e-12
+    acc = (com[2:] - 2.0 * com[1:-1] + com[:-2]) * fps ** 2
+    fl = [n for n in range(1, N - 1) if st[n - 1:n + 2].sum() == 0]
+    A = acc[[n - 1 for n in fl]]
+    assert len(fl) == 14 and abs(np.linalg.norm(A.mean(0)) - 9.81) < 0.015 * 9.81 and np.abs(np.linalg.norm(A, axis=1) - 9.81).max() < 0.06 * 9.81
