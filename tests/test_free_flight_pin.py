@@ -50,3 +50,31 @@ def test_centre_of_mass_falls_with_g_in_the_flight_phases_of_the_stored_physics_
     assert np.abs(np.linalg.norm(Au, axis=1) - G).max() > 0.25 * G
     # control: the wrong frame rate (120 instead of 90 fps) scales the acceleration by 16 / 9
     assert abs(np.linalg.norm(mean) * (120.0 / 90.0) ** 2 - G) > 0.7 * G
+
+
+@pytest.mark.parametrize("fixture", ["kinetic_pin_phantom2017.npz", "kinetic_pin_phantom0902.npz"])
+def test_contact_rules_hold_in_the_stored_physics_results(oracle, fixture):
+    """The reference's physics-based model keeps a foot within `height_uncertainty_m` = 0.1 m of the ground and (nearly) still while it is in one of
+    the stored contact windows (acinoset_opt.py:780-812: `foot_height` bounds, `gamma <= 1`).  This repository reads "foot" as the hock-bottom
+    markers (skeleton.FOOT_MARKERS).  On the reference's own stored results those markers behave as the rules say: inside the windows
+    they stay in a band of 0.13 m around the median stance height and move at ~1 m/s (2.2 at most, backward differences at 90 fps); outside they
+    are 0.13 m up (median) and move at ~9.5 m/s.  Another marker choice, or windows shifted by a few frames, would not show this."""
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    q, fps, st, up = Z["q"], float(Z["fps"]), Z["stance"], Z["ground_normal"]
+    sk = skeleton.build_skeleton("phantom", 24)
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    P = oracle.markers(sk, q)[:, feet]
+    on = st == 1
+    on[0] = False
+    off = (st == 0) & (np.arange(len(q))[:, None] > 0)
+    hgt = P @ up
+    hgt = hgt - np.median(hgt[on])
+    v = np.zeros_like(P); v[1:] = (P[1:] - P[:-1]) * fps
+    vh = v - np.einsum("nkd,d->nk", v, up)[..., None] * up
+    speed = np.linalg.norm(vh, axis=-1)
+    assert on.sum() == 36                                                          # four windows of nine frames
+    assert hgt[on].min() > -0.03 and hgt[on].max() < 0.12 and np.median(hgt[off]) > 0.12
+    assert np.median(speed[on]) < 1.3 and speed[on].max() < 2.2 and np.median(speed[off]) > 8.0
+    # control: the same windows moved by five frames catch the paws in the air
+    sh = np.roll(on, 5, axis=0); sh[:5] = False
+    assert np.median(speed[sh]) > 2.0 * np.median(speed[on])
