@@ -1256,6 +1256,11 @@ static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* o
     std::vector<double> hd;
     if (kstats) hd.resize(2 * F * KIN_STAT);
     if (kstats) HIPCHK(hipMemcpyAsync(hd.data(), h->dstat, sizeof(double) * 2 * F * KIN_STAT, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int> hit;                                  // last word of every node's meta record: Newton iterations of its force solve
+    if (kstats) {
+        hit.resize(2 * F);
+        HIPCHK(hipMemcpy2DAsync(hit.data(), sizeof(int), h->pmeta + KIN_LS, sizeof(int) * (KIN_LS + 1), sizeof(int), 2 * F, hipMemcpyDeviceToHost, h->stream));
+    }
     if (slack)
         for (int b = 0; b < B; b++)
             HIPCHK(hipMemcpy2DAsync(slack + (size_t)b * N * m.nq, sizeof(double) * m.nq, h->slackb + ((size_t)hs[b].cur * F + (size_t)b * N) * CPE_MAX_NQ,
@@ -1280,6 +1285,7 @@ static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* o
                 const double* d = hd.data() + ((size_t)S.cur * F + (size_t)b * N + n) * KIN_STAT;
                 k.cost_eom += d[0]; k.cost_torque += d[1]; k.cost_energy += d[3];
                 k.max_slack = std::max(k.max_slack, d[5]); k.max_base_rows = std::max(k.max_base_rows, d[6]); k.max_violation = std::max(k.max_violation, d[7]);
+                k.inner_max = std::max(k.inner_max, hit[(size_t)S.cur * F + (size_t)b * N + n]);
             }
         }
     }

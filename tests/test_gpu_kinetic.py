@@ -67,6 +67,7 @@ def test_short_gallops_match_oracle(oracle, gpu_handle_factory):
         assert np.abs(r["tau"][b] - ro["tau"]).max() < 1e-4 and np.abs(r["grf"][b] - ro["grf"]).max() < 1e-4 and np.abs(r["slack"][b] - ro["slack"]).max() < 1e-5
         assert abs(ks.cost_eom - kso.cost_eom) < 1e-6 * max(kso.cost_eom, 1e-6) + 1e-9 and abs(ks.cost_torque - kso.cost_torque) < 1e-6 * kso.cost_torque
         assert ks.max_slack < ko.slack_bound and ks.max_violation < 1e-4
+        assert 1 <= ks.inner_max <= ko.inner_iterations                          # Newton iterations of the node force solves are reported
 
 
 def test_prescribed_foot_forces_match_oracle(oracle, gpu_handle_factory):
