@@ -271,8 +271,8 @@ cpe_status cpe_grf_fit(cpe_handle* h, const cpe_grf_options* opt, int32_t B, int
  * row of angle a of link i = f_i . (dR_i/da c_i) + sum over the children c of i  F_subtree(c) . (dR_i/da attach_c)
  *                            + (I_i alpha_i + w_i x I_i w_i) . dw_i/dq'_a,     f_j = m_j (P_j'' + g e_z).
  * What the reference balances these rows against (motor torques, the 26 joint constraint forces, contact forces, slack) is
- * not built yet; this is the evaluation kernel those terms will be added to.  link_inertia: principal moments of every link
- * about its body axes.  Device pointers. */
+ * cpe_dyn_forces / cpe_eom_residual below, and the solve with all of them as unknowns is cpe_solve_kinetic.  link_inertia:
+ * principal moments of every link about its body axes.  Device pointers. */
 typedef struct cpe_eom_options {
     double gravity;
     double link_inertia[CPE_MAX_LINKS][3];
