@@ -151,6 +151,25 @@ def test_remaining_stored_sequences(oracle, fixture, animal, n_frames, missing_c
     assert max(np.abs(oracle.constraints(sk, x)).max() for x in Zs["q"]) < 1e-12
 
 
+@pytest.mark.parametrize("key,n_frames,tol", [("ph17", 44, 5e-4), ("j2", 34, 2e-4), ("ph0902", 45, 5e-5)])
+def test_multi_view_results_of_sibling_sequences_with_cameras_held_fixed(oracle, key, n_frames, tol):
+    """The three sequences that share a rig with a self-calibrated one (`2017_08_29/top/phantom/run1_1`, `.../jules/run1_2` with the cameras of
+    `.../jules/run1_1`; `2017_09_02/top/phantom/run1_2` with those of `.../jules/run1`): their stored MULTI-view results `fte_kinematic/cam*_fte.csv`
+    are reproduced by this repository's FK + the animal's link table with only the pose free per frame -- no camera parameter is fitted to them
+    (tests/golden/fk_fixed_cameras_pin.npz, `tools/pin_contacts_from_csv.py <seq> <animal> <camera fixture> fte_kinematic ...`).  With this every
+    multi-view result the reference ships is pinned (7 self-calibrated + 3 here)."""
+    Zf = np.load(os.path.join(os.path.dirname(__file__), "golden", "fk_fixed_cameras_pin.npz"))
+    uv, q = Zf[key + "_uv"], Zf[key + "_q"]
+    assert uv.shape == (n_frames, 6, 24, 2) and float(Zf[key + "_worst_px"]) < tol
+    sk = skeleton.build_skeleton(str(Zf[key + "_animal"]), 24)
+    cams = _cams(np.load(os.path.join(os.path.dirname(__file__), "golden", str(Zf[key + "_cams"]))))
+    pos = oracle.markers(sk, q)
+    got = np.array([[[oracle.project(cams[c], pos[n, l]) for l in range(24)] for c in range(6)] for n in range(n_frames)])
+    ok = ~np.isnan(uv).any(-1)
+    assert ok.mean() > 0.95 and np.abs(got - uv)[ok].max() < tol
+    assert max(np.abs(oracle.constraints(sk, x)).max() for x in q) < 1e-12
+
+
 def test_numpy_host_fk_agrees_on_the_recovered_angles():
     sk = skeleton.build_skeleton(str(Z["animal"]), 24)
     cams = _cams()
