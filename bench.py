@@ -60,6 +60,42 @@ def lm_flops_per_frame_iteration(nu=28, pb=3):
     return chol + panel + trail + rhs
 
 
+def _gen_sequence(job):
+    """one synthetic sequence (numpy only; runs in a worker process forked before anything touches the GPU)"""
+    kind, L, cam_sel, N, seed = job
+    from cheetah_pose_estimation_amd import abi, skeleton, synth
+    cams = synth.make_cameras(6)
+    if cam_sel is not None:
+        cams = (abi.Camera * len(cam_sel))(*[cams[c] for c in cam_sel])
+    if kind == "gallop":
+        sk = skeleton.without_motion_model(skeleton.build_skeleton("phantom", L))
+        return synth.make_gallop_batch(sk, cams, B=1, N=N, seed=seed)
+    return synth.make_batch(skeleton.build_skeleton("phantom", L), cams, B=1, N=N, seed=seed)
+
+
+def make_sequences(kind, L, cam_sel, N, seeds, workers):
+    """sequence with global index b is generated from its own seed -- no tiling.  Host generation costs 9 ms (18 ms for the
+    planted gallop) per sequence: spread over `workers` forked processes (numpy only) when there are many."""
+    jobs = [(kind, L, cam_sel, N, int(sd)) for sd in seeds]
+    parts = None
+    if workers > 1 and len(jobs) >= 64:
+        try:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(workers) as pool:
+                parts = pool.map(_gen_sequence, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+        except Exception:
+            parts = None
+    if parts is None:
+        parts = [_gen_sequence(j) for j in jobs]
+    return {k: np.ascontiguousarray(np.concatenate([p_[k] for p_ in parts])) for k in parts[0]}
+
+
+def upload(torch, d, dev, keys=("q_true", "q_init", "meas", "weight")):
+    out = {k: torch.tensor(d[k], device=dev) for k in keys if k in d}
+    torch.cuda.synchronize(dev)            # the handle launches on its own stream: nothing of the above may still be in flight
+    return out
+
+
 def tile_batch(torch, d, B, dev, seed):
     """Upload P unique sequences and tile them to B on the device (q gets a small seeded perturbation so
     no two sequences are bit-identical)."""
@@ -149,6 +185,169 @@ def cpu_baseline(sk, cams, opts, d, budget_s=8.0):
                                   solves_per_s=nb / tm, solve_sample=f"{nb} sequences on {us} threads, {tm:.1f} s, {float(its.mean()):.1f} iterations on average"))
 
 
+def roof_bytes(nbytes, ms):
+    """algorithmic bytes over kernel milliseconds against the HBM peak"""
+    if not ms:
+        return None
+    return {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / HBM_PEAK}
+
+
+def roof_flops(nflops, ms):
+    if not ms:
+        return None
+    return {"bound": "fp64", "achieved": nflops / (ms * 1e-3) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s", "frac": nflops / (ms * 1e-3) / FP64_PEAK}
+
+
+def bench_cfg3(torch, _lib, abi, skeleton, synth, dev, local, d3, N, cpu=True):
+    """config 3: monocular -- camera 3 of the rig --, Gaussian-mixture pose prior + window-4 autoregressive motion prior, 24 markers,
+    B unique sequences (seed 1234 + b).  Solves/s of cpe_solve, per-kernel milliseconds from the handle's HIP-event profile of the untimed
+    warm-up solve, bytes / fp64 rooflines per kernel, CPU oracle beside it.  Returns (dict, solved q for the config-4 leg)."""
+    from cheetah_pose_estimation_amd import priors
+    sk = skeleton.build_skeleton("phantom", 24)
+    cams6 = synth.make_cameras(6)
+    cam1 = (abi.Camera * 1)(cams6[2])
+    opts = abi.default_options(120.0)
+    pr = priors.load_priors()
+    h = _lib.Handle(sk, cam1, opts, pr, device=local)
+    B = d3["q_init"].shape[0]
+    T = upload(torch, d3, dev, keys=("q_init", "meas", "weight"))
+    q = torch.empty_like(T["q_init"]); dq = torch.empty_like(q); ddq = torch.empty_like(q)
+    pos = torch.empty((B, N, 24, 3), dtype=torch.float64, device=dev); me = torch.empty((B, N, 1, 24, 2), dtype=torch.float64, device=dev)
+    h.profile(True)
+    _, wstats = h.solve(T["q_init"], T["meas"], T["weight"], q, dq, ddq, pos, me)
+    prof = h.profile_totals()
+    h.profile(False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    _, stats = h.solve(T["q_init"], T["meas"], T["weight"], q, dq, ddq, pos, me)
+    h.synchronize()
+    el = time.perf_counter() - t0
+    its = np.array([s_.iterations for s_ in stats]); stt = np.array([s_.status for s_ in stats])
+    wfi = float((np.array([s_.iterations for s_ in wstats]) + 1).sum()) * N        # frame-iterations of the profiled run
+    nu, nq, nrev, pb = 28, sk.nq, 12, 4
+    fn_b, lm_b = solve_bytes_per_frame_iteration(1, 24, nq, nu, nrev, pb)
+    lm_b += 8 * pb * nu * nu                                  # k_lm_step<4> also reads the prior's off-diagonal blocks
+    lr_b = 8 * ((nq + nrev) + 4 * nrev + pb * nu * nu + nu * nu + 2 * nu + 2 * nu + 8)   # k_lr_band: state + Gamma in; 4 blocks out; diagonal block, gradient read-modify-write; cost
+    ms = {k: v[0] for k, v in prof.items()}; nl = {k: v[1] for k, v in prof.items()}
+    lm_ms = ms.get("k_lm_step", 0.0) + ms.get("k_lm_back", 0.0)
+    kern = {"k_lm_step<4> + k_lm_back<4>": dict(ms_total=lm_ms, launches=nl.get("k_lm_step", 0), bytes_per_frame_iteration=lm_b,
+                                                 roofline=roof_bytes(lm_b * wfi, lm_ms), fp64=roof_flops(lm_flops_per_frame_iteration(nu, pb) * wfi, lm_ms)),
+            "k_lr_band": dict(ms_total=ms.get("k_lr_band", 0.0), launches=nl.get("k_lr_band", 0), bytes_per_frame_iteration=lr_b, roofline=roof_bytes(lr_b * wfi, ms.get("k_lr_band", 0.0))),
+            "k_frame_normal": dict(ms_total=ms.get("k_frame_normal", 0.0), launches=nl.get("k_frame_normal", 0), bytes_per_frame_iteration=fn_b,
+                                   roofline=roof_bytes(fn_b * wfi, ms.get("k_frame_normal", 0.0)))}
+    out = dict(value=B / el, unit="solves/s", workload="cfg3: 200 frames x 1 camera x 24 markers, GMM pose prior + window-4 motion prior, seed 1234 + b",
+               batch=B, seconds=el, iterations_mean=float(its.mean()), iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()),
+               kernels=kern, roofline=kern["k_lm_step<4> + k_lm_back<4>"]["roofline"])
+    if cpu:
+        from oracle import oracle as O
+        O.lib()
+        t1 = time.perf_counter()
+        r1 = O.solve(sk, cam1, opts, pr, d3["q_init"][0], d3["meas"][0], d3["weight"][0])
+        ts = time.perf_counter() - t1
+        cores = min(16, usable_cores()[0])
+        nb = min(B, cores)
+        t2 = time.perf_counter()
+        us, _, itc = O.solve_batch(sk, cam1, opts, d3["q_init"][:nb], d3["meas"][:nb], d3["weight"][:nb], threads=cores, priors=pr)
+        tm = time.perf_counter() - t2
+        out["cpu_baseline"] = dict(value=1.0 / ts, unit="solves/s", cores=1, kind="port", sample=f"sequence 0 of the same batch, oracle/cpe_oracle.c, {ts:.1f} s, {int(r1['stats'].iterations)} iterations",
+                                   multi_thread=dict(value=nb / tm, unit="solves/s", cores=us, sample=f"{nb} sequences, OpenMP over sequences, {tm:.1f} s, {float(itc.mean()):.1f} iterations on average"))
+    qh = q.cpu().numpy()
+    h.close()
+    return out, qh
+
+
+def kinetic_flops_per_node(nq=54, nrow=138, nlat=60, nc3=84, nx=48):
+    """fp64 flops of the dense algebra of one node of the physics-based model per LM iteration (the derivative evaluations are counted by the
+    kernel's own note, not here): Gram matrix A^T A, its Cholesky, J^T W J (lower triangle), A^T J_e, the Schur complement"""
+    gram = nq * nlat * nlat
+    chol = nx ** 3 / 3.0 + nlat ** 3 / 3.0
+    jtj = nrow * nc3 * nc3
+    afj = 2 * nq * nlat * nc3
+    schur = nlat * nlat * nc3 + nlat * nc3 * nc3
+    return dict(k_dyn_eval=gram + chol, k_dyn_assemble=jtj + afj, k_dyn_schur=schur + nlat ** 3 / 3.0)
+
+
+def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu=True):
+    """config 4: physics-based model, phantom skeleton, N = 200, rotary gallop at 3 Hz with 12-frame stance, B unique sequences
+    (seed 4321 + b), warm-started from the kinematic solve of the same measurements as the reference does (acinoset_opt.py:739-777).
+    n_cams = 1: monocular with the pose prior, the way run_dataset.py:1198-1229 runs it; 6: the multi-view variant."""
+    from cheetah_pose_estimation_amd import priors
+    sk = skeleton.build_skeleton("phantom", 24)
+    skk = skeleton.without_motion_model(sk)
+    cams6 = synth.make_cameras(6)
+    cams = (abi.Camera * 1)(cams6[2]) if n_cams == 1 else cams6
+    pr_kin = priors.load_priors() if n_cams == 1 else None
+    pr_dyn = priors.load_priors(pose=True, motion=False) if n_cams == 1 else None
+    B = d4["q_init"].shape[0]
+    T = upload(torch, d4, dev, keys=("q_init", "meas", "weight"))
+    stance = torch.tensor(np.ascontiguousarray(d4["stance"], dtype=np.int32), device=dev)
+    E = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+    q, dq, ddq, pos, me = E(B, N, sk.nq), E(B, N, sk.nq), E(B, N, sk.nq), E(B, N, 24, 3), E(B, N, n_cams, 24, 2)
+    hk = _lib.Handle(sk, cams, abi.default_options(120.0), pr_kin, device=local)
+    _, kst = hk.solve(T["q_init"], T["meas"], T["weight"], q, dq, ddq, pos, me)          # the kinematic estimate = the warm start
+    hk.synchronize(); hk.close()
+    q0 = q.clone()
+    opts = abi.default_options(120.0); opts.tol_cost, opts.max_iter = 1e-7, 600
+    ko = abi.default_kinetic_options(skeleton.dyn_options("phantom"), 120.0)
+    h = _lib.Handle(skk, cams, opts, pr_dyn, device=local)
+    nm, nf, nc = ko.dyn.n_motors, ko.dyn.n_feet, h.n_constraint_rows()
+    tau, lam, grf, slack = E(B, N, nm), E(B, N, nc), E(B, N, nf, 5), E(B, N, sk.nq)
+    h.profile(True)
+    _, wstats, _ = h.solve_kinetic(ko, q0, T["meas"], T["weight"], stance, q, dq, ddq, pos, me, tau, lam, grf, slack)
+    prof = h.profile_totals()
+    h.profile(False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    _, stats, ks = h.solve_kinetic(ko, q0, T["meas"], T["weight"], stance, q, dq, ddq, pos, me, tau, lam, grf, slack)
+    h.synchronize()
+    el = time.perf_counter() - t0
+    its = np.array([s_.iterations for s_ in stats]); stt = np.array([s_.status for s_ in stats])
+    wni = float((np.array([s_.iterations for s_ in wstats]) + 1).sum()) * (N - 2)    # node-iterations of the profiled run
+    nrow, nlat, nc3, nq = sk.nq + 3 * nf + 3 * 24, nm + nc + 3 * nf, 84, sk.nq
+    KP = nc3 * nc3 + 64 * nc3 + 64 * 64
+    byts = dict(k_dyn_eval=8 * (3 * 66 + 64 + 68 + nrow * nc3 + 2 * nrow + nq * 64 + 64 * 64 + 64 + 8 + nq),      # states, warm start, multipliers in; J, row gradient / weight, A, H_ff, forces, record, slack out
+                k_dyn_assemble=8 * (nrow * nc3 + 2 * nrow + nq * 64 + nc3 * nc3 + 64 * nc3 + nc3),                 # J, A in; H_uu, H_fu, gradient out
+                k_dyn_schur=8 * (KP + 64 + 68 + 6 * 28 * 28),                                                       # the three pieces in; six blocks out
+                k_dyn_gather=8 * (3 * 6 * 28 * 28 + 28 * 28 + 3 * nc3 + 28 + 28 * 28 + 3 * 28 * 28 + 28))           # three nodes' blocks in; band blocks + gradient out
+    fl = kinetic_flops_per_node(nq, nrow, nlat, nc3, nm + nc)
+    ms = {k: v[0] for k, v in prof.items()}; nl = {k: v[1] for k, v in prof.items()}
+    kern = {}
+    for k in ("k_dyn_eval", "k_dyn_assemble", "k_dyn_schur", "k_dyn_gather"):
+        kern[k] = dict(ms_total=ms.get(k, 0.0), launches=nl.get(k, 0), bytes_per_node_iteration=byts[k], roofline=roof_bytes(byts[k] * wni, ms.get(k, 0.0)),
+                       fp64=roof_flops(fl[k] * wni, ms.get(k, 0.0)) if k in fl else None)
+    for k in ("k_frame_normal", "k_lm_step", "k_lm_back"):
+        kern[k] = dict(ms_total=ms.get(k, 0.0), launches=nl.get(k, 0))
+    tot = sum(v["ms_total"] for v in kern.values())
+    dom = max(("k_dyn_eval", "k_dyn_assemble", "k_dyn_schur", "k_dyn_gather"), key=lambda k: kern[k]["ms_total"])
+    out = dict(value=B / el, unit="solves/s", workload=f"cfg4: physics-based model, 200 frames x {n_cams} camera(s) x 24 markers, rotary gallop 3 Hz, 12-frame stance, seed 4321 + b"
+               + (", pose prior, monocular warm start" if n_cams == 1 else ""),
+               batch=B, seconds=el, iterations_mean=float(its.mean()), iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()),
+               warm_start_converged_frac=float(np.mean([s_.status == 0 for s_ in kst])), max_slack=float(max(k_.max_slack for k_ in ks)),
+               kernels=kern, kernel_ms_sum=tot, dominant_kernel=dom, roofline=kern[dom]["roofline"])
+    if cpu:
+        from oracle import oracle as O
+        O.lib()
+        q0h = q0[0].cpu().numpy()
+        t1 = time.perf_counter()
+        ro = O.solve_kinetic(skk, cams, opts, pr_dyn, ko, q0h, d4["meas"][0], d4["weight"][0], d4["stance"][0])
+        tm = time.perf_counter() - t1
+        cores = min(16, usable_cores()[0])
+        # one thread on a bounded sample: the first 40 frames of the same sequence (a 200-frame solve on one thread takes minutes)
+        n1 = 40
+        os.environ["CPO_THREADS"] = "1"
+        t2 = time.perf_counter()
+        r1 = O.solve_kinetic(skk, cams, opts, pr_dyn, ko, q0h[:n1], d4["meas"][0][:n1], d4["weight"][0][:n1], d4["stance"][0][:n1])
+        t1s = time.perf_counter() - t2
+        del os.environ["CPO_THREADS"]
+        rm = float(np.sqrt(((pos[0].cpu().numpy() - ro["positions"]) ** 2).sum(-1).mean()))
+        out["cpu_baseline"] = dict(value=1.0 / tm, unit="solves/s", cores=cores, kind="port",
+                                   sample=f"sequence 0 of the same batch, oracle/cpe_oracle_kinetic.inc, OpenMP over nodes, {tm:.1f} s, {int(ro['stats'].iterations)} iterations",
+                                   single_thread=dict(frames_per_s=n1 / t1s, unit="frames/s", cores=1, sample=f"first {n1} frames of that sequence, {t1s:.1f} s, {int(r1['stats'].iterations)} iterations"),
+                                   rmse_gpu_vs_oracle_m=rm)
+    h.close()
+    return out
+
+
 def pmc_traffic(B, N, C, L, kernel="k_resjac"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc*.json, tools/summarise_pmc.py: separate
     FETCH_SIZE / WRITE_SIZE runs, read side doubled per MI355X_MICROARCH.md), scaled per frame.  The newest round's file wins.
@@ -202,6 +401,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
     ap.add_argument("--no-l24", action="store_true", help="skip the extra 24-marker residual+Jacobian measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 (monocular + learned priors) and config-4 (physics-based) solve timings")
+    ap.add_argument("--cfg3-batch", type=int, default=256)
+    ap.add_argument("--cfg4-batch", type=int, default=16)
+    ap.add_argument("--cfg4-cams", type=int, default=6, choices=(1, 6), help="cameras of the physics-based timing (1 = monocular + pose prior, as the reference runs it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -237,6 +440,21 @@ def main():
     rehearsal = os.environ.get("CPE_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+    L, N, C = args.markers, args.frames, 6
+    sk = skeleton.build_skeleton("phantom", L)
+    cams = synth.make_cameras(C)
+    opts = abi.default_options(120.0)
+    # ---- synthetic inputs, generated BEFORE this process touches the GPU (the generator forks numpy-only workers).  SURVEY 8d: the sequence with
+    # global index b has seed 1234 + b; the global list is dealt to the ranks round-robin: no two ranks (and no two slots of a rank) share one
+    B = args.batch
+    Bgen = max(B, 0 if args.no_solve else args.solve_batch)
+    workers = max(1, min(16, usable_cores()[0] // max(1, min(world, 8))))
+    mine = sharding.shard_indices(world * Bgen, rank, world)
+    d = make_sequences("run", L, None, N, [1234 + int(i) for i in mine], workers)
+    d24 = make_sequences("run", 24, None, N, [1234 + int(i) for i in mine[:B]], workers) if (L == 25 and world == 1 and not args.no_l24) else None
+    extra = world == 1 and not args.no_solve and not args.no_extra
+    d3 = make_sequences("run", 24, [2], N, [1234 + i for i in range(args.cfg3_batch)], workers) if extra else None
+    d4 = make_sequences("gallop", 24, [2] if args.cfg4_cams == 1 else None, N, [4321 + i for i in range(args.cfg4_batch)], workers) if extra else None
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -253,19 +471,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    L, N, C = args.markers, args.frames, 6
-    sk = skeleton.build_skeleton("phantom", L)
-    cams = synth.make_cameras(C)
-    opts = abi.default_options(120.0)
     h = _lib.Handle(sk, cams, opts, device=local)
     S = h.S
-    P = 32
-    # the global list of unique sequences (seed 1234 + index) is dealt to the ranks round-robin: no two ranks own the same one
-    mine = sharding.shard_indices(world * P, rank, world)
-    parts = [synth.make_batch(sk, cams, B=1, N=N, seed=1234 + i) for i in mine]
-    d = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
-    B = args.batch
-    t = tile_batch(torch, d, B, dev, seed=rank)
+    t = upload(torch, {k: v[:B] for k, v in d.items()}, dev)
     r = torch.empty((B, N, C, L, 2), dtype=torch.float64, device=dev)
     J = torch.empty((B, N, C, S, 2), dtype=torch.float64, device=dev)
     eps = torch.empty((B, N, sk.nq), dtype=torch.float64, device=dev)
@@ -309,12 +517,11 @@ def main():
 
     # "also report L=24" -- the reference's own 24 markers, same cameras and sequence shape, same kernel
     l24 = None
-    if L == 25 and world == 1 and not args.no_l24:
+    if d24 is not None:
         del r, J, eps
         sk24 = skeleton.build_skeleton("phantom", 24)
         h24 = _lib.Handle(sk24, cams, opts, device=local)
-        d24 = synth.make_batch(sk24, cams, B=P, N=N, seed=1234)
-        t24 = tile_batch(torch, d24, B, dev, seed=7)
+        t24 = upload(torch, d24, dev)
         r = torch.empty((B, N, C, 24, 2), dtype=torch.float64, device=dev)
         J = torch.empty((B, N, C, h24.S, 2), dtype=torch.float64, device=dev)
         eps = torch.empty((B, N, sk24.nq), dtype=torch.float64, device=dev)
@@ -331,7 +538,8 @@ def main():
     solves = None
     if not args.no_solve:
         Bs = args.solve_batch
-        ts_ = tile_batch(torch, d, Bs, dev, seed=100 + rank)
+        del t
+        ts_ = upload(torch, {k: v[:Bs] for k, v in d.items()}, dev, keys=("q_init", "meas", "weight"))
         r = J = eps = cost = None
         q = torch.empty((Bs, N, sk.nq), dtype=torch.float64, device=dev); dq = torch.empty_like(q); ddq = torch.empty_like(q)
         pos = torch.empty((Bs, N, L, 3), dtype=torch.float64, device=dev); me = torch.empty((Bs, N, C, L, 2), dtype=torch.float64, device=dev)
@@ -393,6 +601,15 @@ def main():
                 lat[f"N{n1}"] = dict(ms=1e3 * float(np.median(times[1:])), iterations=int(s1[0].iterations), status=int(s1[0].status))
             solves["latency_b1"] = lat
 
+    cfg3 = cfg4 = None
+    if extra:
+        h.close()                                          # its 16 GB workspace goes back before the next handles are made
+        ts_ = q = dq = ddq = pos = me = None
+        torch.cuda.empty_cache()
+        cfg3, q3 = bench_cfg3(torch, _lib, abi, skeleton, synth, dev, local, d3, N, cpu=not args.no_cpu)
+        cfg4 = bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, args.cfg4_cams, cpu=not args.no_cpu)
+        h = None
+
     if rank == 0:
         bpf = resjac_bytes_per_frame(C, L, S, sk.nq, False)
         ach = bpf * B * N / (kern_ms * 1e-3)
@@ -403,7 +620,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2: synthetic 200-frame x 6-cam x 25-marker sequences, phantom skeleton, const-accel model",
                        "frames": N, "cams": C, "markers": L, "sequences_per_gpu": B, "parallelism": f"shard{world} (independent sequences, no collective)"},
-            "solves": solves, "markers24": l24,
+            "solves": solves, "solves_cfg3": cfg3, "solves_cfg4": cfg4, "markers24": l24,
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                          "traffic": pmc_traffic(B, N, C, L), "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
         }
@@ -412,9 +629,10 @@ def main():
             out["with_cost"] = {"kernel": "k_resjac<true>", "kernel_ms": ms_cost, "bytes_per_frame": bc, "value": B * N / (ms_cost * 1e-3),
                                 "frac": bc * B * N / (ms_cost * 1e-3) / HBM_PEAK}
         if not args.no_cpu and world == 1:          # the CPU leg is timed on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(sk, cams, opts, d)
+            out["cpu_baseline"] = cpu_baseline(sk, cams, opts, {k: v[:32] for k, v in d.items()})
         print(json.dumps(out), flush=True)
-    h.close()
+    if h is not None:
+        h.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -161,14 +161,15 @@ class Handle:
     def _leave(self):
         _check(self.lib.cpe_stream_signal(self._h, self._torch_stream()), "cpe_stream_signal")
 
-    PROFILE_SLOTS = ("k_frame_normal", "k_lr_band", "k_lm_step", "k_build_act", "k_finalize", "k_dyn_term", "k_dyn_gather", "k_lm_back")
+    PROFILE_SLOTS = ("k_frame_normal", "k_lr_band", "k_lm_step", "k_build_act", "k_finalize", "k_dyn_eval", "k_dyn_gather", "k_lm_back",
+                     "k_dyn_assemble", "k_dyn_schur", "_free10", "_free11")
 
     def profile(self, on: bool):
         _check(self.lib.cpe_profile_enable(self._h, 1 if on else 0), "cpe_profile_enable")
 
     def profile_totals(self):
         """{kernel: (milliseconds, launches)} accumulated by the solves since profile(True)"""
-        ms = (C.c_double * 8)(); n = (C.c_int64 * 8)()
+        ms = (C.c_double * len(self.PROFILE_SLOTS))(); n = (C.c_int64 * len(self.PROFILE_SLOTS))()
         _check(self.lib.cpe_profile_get(self._h, ms, n), "cpe_profile_get")
         return {k: (ms[i], int(n[i])) for i, k in enumerate(self.PROFILE_SLOTS) if n[i]}
 

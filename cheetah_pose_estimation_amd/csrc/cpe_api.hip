@@ -53,6 +53,7 @@ struct cpe_handle {
     DevKin* dk = nullptr; DevKin hk;
     size_t kws_frames = 0;
     double *kmut = nullptr;       // multipliers of the torque boxes [F][2 CPE_MAX_MOTORS] (cpe_solve_kinetic_bounded)
+    double *kmus = nullptr;       // multipliers of the box on the residual [F][2 CPE_MAX_NQ] (bound_eom_error)
     double *fbuf = nullptr, *kmu = nullptr, *Jbuf = nullptr, *Abuf = nullptr, *pieces = nullptr, *gTb = nullptr, *dstat = nullptr, *slackb = nullptr,
            *Tbuf = nullptr, *gk = nullptr, *Bk = nullptr, *Hk = nullptr;
     int* pmeta = nullptr;
@@ -493,9 +494,9 @@ cpe_status cpe_create(const cpe_skeleton* skel, const cpe_camera* cams, int32_t 
 }
 
 static void free_kws(cpe_handle* h) {
-    void* ptrs[] = {h->kmut, h->fbuf, h->kmu, h->Jbuf, h->Abuf, h->pieces, h->gTb, h->dstat, h->slackb, h->Tbuf, h->gk, h->Bk, h->Hk, h->pmeta};
+    void* ptrs[] = {h->kmut, h->kmus, h->fbuf, h->kmu, h->Jbuf, h->Abuf, h->pieces, h->gTb, h->dstat, h->slackb, h->Tbuf, h->gk, h->Bk, h->Hk, h->pmeta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    h->kmut = h->fbuf = h->kmu = h->Jbuf = h->Abuf = h->pieces = h->gTb = h->dstat = h->slackb = h->Tbuf = h->gk = h->Bk = h->Hk = nullptr; h->pmeta = nullptr;
+    h->kmut = h->kmus = h->fbuf = h->kmu = h->Jbuf = h->Abuf = h->pieces = h->gTb = h->dstat = h->slackb = h->Tbuf = h->gk = h->Bk = h->Hk = nullptr; h->pmeta = nullptr;
     h->kws_frames = 0;
 }
 
@@ -1051,7 +1052,8 @@ cpe_status cpe_solve_shutter(cpe_handle* h, int32_t B, int32_t N, const double* 
 void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kinetic_dataset) {
     // o->dyn (inertias, feet, motors) is the caller's
     o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
-    o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->slack_bound = 2.0;
+    o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->zvel_max = kinetic_dataset ? 1.0 : 0.0;
+    o->slack_lo = -2.0; o->slack_hi = 2.0; o->kappa_slack = 1e6;
     o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0;
     o->inner_iterations = 30; o->_pad = 0;
 }
@@ -1077,14 +1079,19 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
         for (int t = (m.joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 0 : 1); t < 2; t++) { K.con_joint[K.nc] = j; K.con_axis[K.nc] = t == 0 ? 0 : 2; K.nc++; }
     K.nlat = K.nm + K.nc + 3 * K.nf;
     if (K.nlat > KIN_LS || K.nm + K.nc > 52) return fail(CPE_BAD_ARG, "more than 64 node forces");
-    K.nrow = m.nq + 3 * K.nf + 3 * m.L;
-    if (m.nl > 32 || m.L > 32 || m.nrev > 32 || K.nrow > KIN_ROWS_MAX) return fail(CPE_BAD_ARG, "skeleton too large for the kinetic kernels");
+    K.nrow = m.nq + 4 * K.nf + 3 * m.L;          // slack | foot heights | foot velocities (x, y, z) | second differences of the markers
+    // the evaluation slots of k_dyn_eval are laid out for the reference's skeleton (KS_* in cpe_kinetic.hip.inc): anything larger is refused here,
+    // not truncated there
+    if (m.nq > KS_NQ || m.nl > KS_NL || m.L > KS_L || m.ns > KS_NS || m.nrev > 32 || K.nrow > KS_NROW || K.nrow > KIN_ROWS_MAX)
+        return fail(CPE_BAD_ARG, "skeleton too large for the kinetic kernels (at most 54 coordinates, 17 links, 24 markers)");
     double mt = 0; for (int i = 0; i < m.nl; i++) mt += m.mass[i];
     K.Mg = mt * d.eom.gravity; K.h = h->opts.h; K.ih = 1.0 / h->opts.h;
     for (int i = 0; i < m.nl; i++) { uint32_t mask = 0; for (int j = 0; j < m.nl; j++) { int a = j; while (a >= 0 && a != i) a = m.parent[a]; if (a == i) mask |= 1u << j; } K.sub_mask[i] = mask; }
     K.grf_fix = grf_fix;
     K.grf_box = grf_box;
     K.tau_box = tau_box; K.mu_tau = h->kmut;            // (the workspace is sized before this is called)
+    K.mu_slack = h->kmus; K.sbox = (opt->slack_hi < 1e9 || opt->slack_lo > -1e9) ? 1 : 0;
+    if (K.sbox && (!(opt->kappa_slack > 0) || !(opt->slack_lo < opt->slack_hi))) return fail(CPE_BAD_ARG, "kinetic options: slack box needs lo < hi and a positive penalty");
     if (!h->dk) HIPCHK(hipMalloc(&h->dk, sizeof(DevKin)));
     HIPCHK(hipMemcpyAsync(h->dk, &K, sizeof(DevKin), hipMemcpyHostToDevice, h->stream));
     return CPE_OK;
@@ -1105,6 +1112,7 @@ static cpe_status ensure_kws(cpe_handle* h, int B, int N) {
     HIPCHK(hipMalloc(&h->fbuf, sizeof(double) * 2 * F * KIN_LS));
     HIPCHK(hipMalloc(&h->kmu, sizeof(double) * F * 4 * KIN_MU));
     HIPCHK(hipMalloc(&h->kmut, sizeof(double) * F * 2 * CPE_MAX_MOTORS));
+    HIPCHK(hipMalloc(&h->kmus, sizeof(double) * F * 2 * CPE_MAX_NQ));
     HIPCHK(hipMalloc(&h->Jbuf, sizeof(double) * F * KIN_JSTRIDE));
     HIPCHK(hipMalloc(&h->Abuf, sizeof(double) * F * CPE_MAX_NQ * KIN_LS));
     HIPCHK(hipMalloc(&h->pieces, sizeof(double) * 2 * F * KIN_PIECE));
@@ -1128,6 +1136,8 @@ static void launch_dyn_eval(cpe_handle* h, int N, int first, size_t Fw, const in
     prof_begin(h, 5);
     hipLaunchKernelGGL(k_dyn_eval, dim3(gf), dim3(KIN_THREADS), lds_kin_eval(), h->stream, h->dm, h->dk, h->st, N, first, Fw, h->qbuf, stance, h->fbuf, h->kmu, h->costbuf,
                        h->Jbuf, h->Abuf, h->pieces, h->pmeta, h->dstat, h->slackb, act, n_act);
+    prof_end(h);
+    prof_begin(h, 8);
     hipLaunchKernelGGL(k_dyn_assemble, dim3(gf), dim3(KIN_THREADS), lds_kin_assemble(), h->stream, h->dm, h->dk, h->st, N, first, Fw, h->Jbuf, h->Abuf, h->pieces, h->pmeta,
                        h->gTb, act, n_act);
     prof_end(h);
@@ -1188,6 +1198,7 @@ static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* o
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     HIPCHK(hipMemsetAsync(h->fbuf, 0, sizeof(double) * 2 * F * KIN_LS, h->stream));
     HIPCHK(hipMemsetAsync(h->kmu, 0, sizeof(double) * F * 4 * KIN_MU, h->stream));
+    HIPCHK(hipMemsetAsync(h->kmus, 0, sizeof(double) * F * 2 * CPE_MAX_NQ, h->stream));
     if (tau_box) HIPCHK(hipMemsetAsync(h->kmut, 0, sizeof(double) * F * 2 * CPE_MAX_MOTORS, h->stream));
     LmParams prm;
     prm.tol_step = h->opts.tol_step; prm.tol_cost = h->opts.tol_cost; prm.lambda0 = h->opts.lambda0; prm.B = B; prm.N = N;
@@ -1206,13 +1217,17 @@ static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* o
         hipLaunchKernelGGL((k_lm_step<3, 1>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
                            h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, nullptr, act, n_act, 2, nullptr, h->dgbuf);
         prof_end(h);
-        prof_begin(h, 6);
+        prof_begin(h, 9);
         hipLaunchKernelGGL(k_dyn_schur, dim3(gf), dim3(KIN_THREADS), lds_kin_schur(), h->stream, h->dk, h->st, N, Fw, h->pieces, h->pmeta, h->fbuf, h->kmu, stance, h->Tbuf, act, n_act);
+        prof_end(h);
+        prof_begin(h, 6);
         hipLaunchKernelGGL(k_dyn_gather, dim3(gf), dim3(KIN_THREADS), 0, h->stream, h->st, N, Fw, h->gbuf, h->Bbuf, h->Tbuf, h->gTb, h->gk, h->Bk, h->Hk, act, n_act);
         prof_end(h);
         prof_begin(h, 2);
         hipLaunchKernelGGL((k_lm_step<3, 2>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gk, h->Bk, h->costbuf,
                            h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hk, act, n_act, 1, nullptr, h->dgbuf);
+        prof_end(h);
+        prof_begin(h, 7);
         hipLaunchKernelGGL((k_lm_back<3>), dim3(slots), dim3(2 * WAVE), 0, h->stream, h->dm, h->st, prm, h->qbuf, h->Lbuf, h->zbuf, h->gtbuf, h->dgbuf, act, n_act);
         prof_end(h);
     };
@@ -1298,19 +1313,23 @@ static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* o
 cpe_status cpe_eval_kinetic_nodes(cpe_handle* h, const cpe_kinetic_options* opt, int32_t B, int32_t N, const double* q, const double* meas, const double* weight,
                                   const int32_t* stance, double* f, double* stat, double* g, double* Huu, double* Hfu, double* Hff, int32_t* meta) {
     if (!h || !opt || !q || !meas || !weight || !stance) return fail(CPE_BAD_ARG, "null argument");
+    if (B < 0 || N < 0) return fail(CPE_BAD_ARG, "negative size");
     const size_t F = (size_t)B * N;
     if (F == 0) return CPE_OK;
+    if (F > 0x7fffffffULL) return fail(CPE_BAD_ARG, "too many frames for one launch");
+    if (h->pb != 3) return fail(CPE_BAD_ARG, "the physics-based model runs on the half-bandwidth-3 solver");
     HIPCHK(hipSetDevice(h->device));
-    cpe_status s = build_kin(h, opt);
+    cpe_status s = ensure_ws(h, B, N);                     // the workspaces first: build_kin records pointers into them
     if (s != CPE_OK) return s;
-    if ((s = ensure_ws(h, B, N)) != CPE_OK) return s;
     if ((s = ensure_kws(h, B, N)) != CPE_OK) return s;
+    if ((s = build_kin(h, opt)) != CPE_OK) return s;
     const DevModel& m = h->hm;
     hipLaunchKernelGGL(k_state_init, dim3((unsigned)F), dim3(WAVE), 0, h->stream, h->dm, q, h->qbuf);
     HIPCHK(hipMemsetAsync(h->st, 0, sizeof(SeqState) * B, h->stream));
     HIPCHK(hipMemsetAsync(h->mu, 0, sizeof(double) * (F * (size_t)(m.nb > 0 ? m.nb : 1) * 2), h->stream));
     HIPCHK(hipMemsetAsync(h->fbuf, 0, sizeof(double) * 2 * F * KIN_LS, h->stream));
     HIPCHK(hipMemsetAsync(h->kmu, 0, sizeof(double) * F * 4 * KIN_MU, h->stream));
+    HIPCHK(hipMemsetAsync(h->kmus, 0, sizeof(double) * F * 2 * CPE_MAX_NQ, h->stream));
     hipLaunchKernelGGL(FRAME_NORMAL(h->gmm_k == 0), dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
                        h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr, ShutterArgs{nullptr, nullptr, nullptr});
     launch_dyn_eval(h, N, 1, F, stance, nullptr, nullptr, B);

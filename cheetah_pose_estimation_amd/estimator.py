@@ -597,14 +597,15 @@ def determine_contacts(estimator: CheetahEstimator, monocular: bool = False, ver
     return contacts, by_height
 
 
-def stance_from_contacts(contact_json: dict, n_frames: int, first_frame: int) -> np.ndarray:
-    """contact windows [first, last, foot, label] of `autogen-contact.json` / metadata.json -> stance[N, 4] in skeleton.FEET order: frame
-    first - start_frame ... last - start_frame INCLUSIVE, as `contact_times` of acinoset_opt.py:787-798"""
+def stance_from_contacts(contact_json: dict, n_frames: int) -> np.ndarray:
+    """contact windows [first, last, foot, label] of `autogen-contact.json` / metadata.json -> stance[N, 4] in skeleton.FEET order: node
+    first - start_frame ... last - start_frame INCLUSIVE with start_frame = the CONTACT FILE's own (`contact_times` of acinoset_opt.py:787-798:
+    `(f_contact[0] - start_frame) + 1` in Pyomo's one-based finite elements)"""
     start = contact_json["start_frame"]
     st = np.zeros((n_frames, len(skeleton.FEET)), np.int32)
     for k, foot in enumerate(skeleton.FEET):
         for win in (contact_json["contacts"].get(f"{foot}_foot") or []):
-            a, b = int(win[0]) - start + (start - first_frame), int(win[1]) - start + (start - first_frame)
+            a, b = int(win[0]) - start, int(win[1]) - start
             st[max(a, 0):max(min(b + 1, n_frames), 0), k] = 1
     return st
 
@@ -617,11 +618,22 @@ def load_force_table(path_csv: str) -> Dict[int, np.ndarray]:
     return {int(k): rows[rows[:, 0] == k][:, 2:5] for k in np.unique(rows[:, 0])}
 
 
-def grf_profile(plates: Dict[int, np.ndarray], contact_json: dict, n_frames: int) -> Tuple[np.ndarray, np.ndarray]:
-    """`misc.get_grf_profile` for tables that are already per frame (its `synthetic_data` path, acinoset_misc.py:946-1026): grfz [N, 4] and
-    grfxy [N, 4, 4] (friction-polygon sides +x, +y, -x, -y) in skeleton.FEET order.  As there: only the FIRST contact of a foot (it "assumes a
-    single stride"), frames 0 .. N-2 (`for fe in range(1, nfe)`), the table row is the frame's offset from the contact file's start frame, and of
-    the horizontal force only the LARGEST positive polygon component is kept."""
+def resample_force_plate(x: np.ndarray, up: int = 2, down: int = 35, dc_samples: int = 500) -> np.ndarray:
+    """One channel of the measured force plates (`grf/data.h5`, 3.5 kHz) on the 200 Hz frame grid, as `get_grf_profile(synthetic_data=False)` prepares
+    it for the kinetic dataset (acinoset_misc.py:985-1000): the mean of the first `dc_samples` samples is removed (`remove_dc_offset(x, 500)`, :717-719),
+    then `scipy.signal.resample_poly(x, up=2, down=35)`: zero-stuffing by 2, the default Kaiser-windowed (beta 5) low-pass FIR of half-length
+    10 max(up, down) with cut-off 1 / max(up, down) and gain `up`, decimation by 35, output length ceil(2 len / 35)."""
+    from scipy import signal
+    x = np.asarray(x, dtype=np.float64)
+    return signal.resample_poly(x - np.mean(x[:dc_samples], axis=0), up=up, down=down, axis=0)
+
+
+def grf_profile(plates: Dict[int, np.ndarray], contact_json: dict, n_frames: int, absolute_rows: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """`misc.get_grf_profile` on per-frame tables (acinoset_misc.py:946-1026): grfz [N, 4] and grfxy [N, 4, 4] (friction-polygon sides +x, +y, -x,
+    -y) in skeleton.FEET order.  As there: only the FIRST contact of a foot (it "assumes a single stride"), frames 0 .. N-2
+    (`for fe in range(1, nfe)`), and of the horizontal force only the LARGEST positive polygon component is kept.  Row convention: a synthetic table
+    (`data_synth`) starts at the contact file's start frame -- frame n reads row n (`Fz[fe - 1]`, :1003-1006); the resampled MEASURED plates of the
+    kinetic dataset start with the recording -- frame n reads row start_frame + n (`Fz[start_frame + fe - 1]`, :1007-1010): `absolute_rows=True`."""
     start = contact_json["start_frame"]
     gz = np.zeros((n_frames, len(skeleton.FEET))); gxy = np.zeros((n_frames, len(skeleton.FEET), 4))
     for k, foot in enumerate(skeleton.FEET):
@@ -633,14 +645,40 @@ def grf_profile(plates: Dict[int, np.ndarray], contact_json: dict, n_frames: int
         if F is None:
             continue
         for n in range(n_frames - 1):
-            if first <= start + n <= last and n < len(F):
-                fx, fy, fz = F[n]
+            row = start + n if absolute_rows else n
+            if first <= start + n <= last and 0 <= row < len(F):
+                fx, fy, fz = F[row]
                 gz[n, k] = fz
                 comps = np.array([fx, fy, -fx, -fy])
                 i = int(np.argmax(comps))
                 if comps[i] > 0:
                     gxy[n, k, i] = comps[i]
     return gz, gxy
+
+
+def load_measured_plates(grf_dir: str, direction: float, scale_forces_by: float) -> Optional[Dict[int, np.ndarray]]:
+    """CSV twins of the reference's `grf/data.h5` (PyTables is absent; columns force_plate, sample, Fx, Fy, Fz as `load_force_table` reads them):
+    `data.csv` = one row per video frame from the start of the recording, already resampled and in body weights; `data_3500hz.csv` = the raw 3.5 kHz
+    samples in newtons, resampled here exactly as the reference does (`measured_force_plates`).  None if neither exists."""
+    per_frame = os.path.join(grf_dir, "data.csv")
+    if os.path.exists(per_frame):
+        return load_force_table(per_frame)
+    raw = os.path.join(grf_dir, "data_3500hz.csv")
+    if os.path.exists(raw):
+        return measured_force_plates(load_force_table(raw), direction, scale_forces_by)
+    return None
+
+
+def measured_force_plates(raw: Dict[int, np.ndarray], direction: float, scale_forces_by: float) -> Dict[int, np.ndarray]:
+    """raw {plate: [samples, 3] = (Fx, Fy, Fz) at 3.5 kHz, newtons} -> the per-frame table `grf_profile(..., absolute_rows=True)` reads: every channel
+    resampled by 2 / 35 after its DC offset is removed, Fx and Fy times the running direction, all times `scale_forces_by` = 1 / (M g)
+    (acinoset_misc.py:985-1000)"""
+    out = {}
+    for k, F in raw.items():
+        F = np.asarray(F, dtype=np.float64)
+        out[k] = np.stack([direction * resample_force_plate(F[:, 0]) * scale_forces_by, direction * resample_force_plate(F[:, 1]) * scale_forces_by,
+                           resample_force_plate(F[:, 2]) * scale_forces_by], axis=1)
+    return out
 
 
 def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, auto: bool = True, use_2d_reprojections: bool = True,
@@ -666,6 +704,9 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
         raise AssertionError("Dynamic model of the cheetah is required.")          # the reference asserts hasattr(model, 'eom_f')
     if not use_2d_reprojections:
         raise NotImplementedError("the 3D kinematic cost (use_2d_reprojections=False) is not built")
+    if not est.enable_eom_slack:
+        raise NotImplementedError("enable_eom_slack=False (hard equations of motion, no slack cost, acinoset_opt.py:914): the slack IS the residual of this "
+                                  "solver's least-squares model; no driver of the reference switches it off")
     if params.enable_shutter_delay_estimation and scene.cam_idx is None:
         raise NotImplementedError("shutter delays are estimated by estimate_kinematics only (cpe_solve_shutter); not inside the physics-based model")
     data_dir = params.data_dir if out_dir_prefix is None else os.path.join(out_dir_prefix, est.data_path)
@@ -687,14 +728,21 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     grf_fixed = None
     grf_box = None
     if joint_estimation:
-        stance = stance_from_contacts(contact_json, N, params.start_frame)
+        stance = stance_from_contacts(contact_json, N)
     else:
         if synthesised_grf:                                                          # acinoset_opt.py:814-820
-            table = os.path.join(data_dir if auto else params.data_dir, "grf", "data_synth.csv" if auto else "data.csv")
-            if not os.path.exists(table):
+            measured = (not auto) and params.kinetic_dataset                         # the resampled plates are indexed by absolute frame (acinoset_misc.py:1007-1010)
+            if auto:
+                table = os.path.join(data_dir, "grf", "data_synth.csv")
+                plates = load_force_table(table) if os.path.exists(table) else None
+            else:
+                table = os.path.join(params.data_dir, "grf", "data.csv")
+                direction = 1.0 if float(np.mean(est.com_vel, axis=0)[0]) < 0 else -1.0      # acinoset_opt.py:817
+                plates = load_measured_plates(os.path.join(params.data_dir, "grf"), direction, 1.0 / est.scale_forces_by)
+            if plates is None:
                 raise FileNotFoundError(f"{table}: the force table of the prescribed-force branch (determine_contacts writes grf/data_synth.csv; the measured "
-                                        "force plates ship as grf/data.h5 in the reference, which needs PyTables -- provide a CSV twin)")
-            gz, gxy = grf_profile(load_force_table(table), contact_json, N)
+                                        "force plates ship as grf/data.h5 in the reference, which needs PyTables -- provide a CSV twin, data.csv or data_3500hz.csv)")
+            gz, gxy = grf_profile(plates, contact_json, N, absolute_rows=measured)
         else:                                                                        # :821-822: the per-frame fit
             gzd, gxyd = est.estimate_grf(monocular=True, plot=False, out_dir_prefix=out_dir_prefix)
             gz = np.zeros((N, 4)); gxy = np.zeros((N, 4, 4))
@@ -728,7 +776,7 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     if disable_motion_prior:
         ko.w_torque, ko.w_smooth = 0.0, 0.0                                          # acinoset_opt.py:918-920
     if est.bound_eom_error is not None:
-        ko.slack_bound = float(max(abs(est.bound_eom_error[0]), abs(est.bound_eom_error[1])))
+        ko.slack_lo, ko.slack_hi = float(est.bound_eom_error[0]), float(est.bound_eom_error[1])      # make_pyomo_model(bound_eom_error=...), acinoset_opt.py:510-514
     skk = skeleton.without_motion_model(sk)              # the physics-based cost has no constant-acceleration term (acinoset_opt.py:905-921)
     h = _lib.Handle(skk, est.cams, opts, pri, device=est.device)
     try:
@@ -754,9 +802,9 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     if solver_output:
         print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- pose: {st.cost_pose}\n-- energy: {ks.cost_energy}\n-- eom_error: {ks.cost_eom}\n"
               f"-- torque: {ks.cost_torque}\nstatus {st.status}, {st.iterations} LM iterations, {st.outer} multiplier updates, {est.opt_time_s:.3f} s\n"
-              f"max |slack_eom| {ks.max_slack:.3e} (bound {ko.slack_bound}), max |rows 0-2| / Mg {ks.max_base_rows:.3e}, max violated inequality {ks.max_violation:.3e}\n"
+              f"max |slack_eom| {ks.max_slack:.3e} (box [{ko.slack_lo}, {ko.slack_hi}]), max |rows 0-2| / Mg {ks.max_base_rows:.3e}, max violated inequality {ks.max_violation:.3e}\n"
               f"RMSE base: {base_err:.4f}\nRMSE links: {rel_err:.4f}")
-    ok = st.status == abi.OK and ks.max_slack <= ko.slack_bound
+    ok = st.status == abi.OK and bool((res["slack"][0] >= ko.slack_lo - 1e-4).all() and (res["slack"][0] <= ko.slack_hi + 1e-4).all())
     if scene.cam_idx is not None or ok:                                              # acinoset_opt.py:948-954
         dname = f"fte_kinetic{'_gt' if params.hand_labeled_data else ''}"
         dname = dname if scene.cam_idx is None else f"{dname}_{scene.cam_idx}"
@@ -801,9 +849,10 @@ def estimate_grf(estimator: CheetahEstimator, solver_output: bool = True, out_di
     tau_box = bound_value(init_tau, 0.1)
     with open(os.path.join(params.data_dir, "metadata.json"), "r", encoding="utf-8") as fh:
         contact_json = json.load(fh)
-    table = os.path.join(params.data_dir, "grf", "data.csv")
-    if os.path.exists(table):
-        gz, _ = grf_profile(load_force_table(table), contact_json, N)
+    direction = 1.0 if float(np.mean(np.asarray(fte["com_vel"]), axis=0)[0]) < 0 else -1.0
+    plates = load_measured_plates(os.path.join(params.data_dir, "grf"), direction, 1.0 / est.scale_forces_by)
+    if plates is not None:
+        gz, _ = grf_profile(plates, contact_json, N, absolute_rows=True)                # measured plates: row = absolute frame
         stance = (gz != 0).astype(np.int32)
     else:
         stance = np.zeros((N, len(skeleton.FEET)), np.int32)
@@ -821,7 +870,7 @@ def estimate_grf(estimator: CheetahEstimator, solver_output: bool = True, out_di
         ko.foot_height_tol = 0.03                                                    # foot_height in [-0.03, 0.03] during a contact (:1010-1012)
         ko.slip_max = 0.0                                                            # this NLP has no no-slip rule (estimate_kinetics adds it to ITS model)
     if est.bound_eom_error is not None:
-        ko.slack_bound = float(max(abs(est.bound_eom_error[0]), abs(est.bound_eom_error[1])))
+        ko.slack_lo, ko.slack_hi = float(est.bound_eom_error[0]), float(est.bound_eom_error[1])      # make_pyomo_model(bound_eom_error=...), acinoset_opt.py:510-514
     skk = skeleton.without_motion_model(sk)
     h = _lib.Handle(skk, est.cams, opts, None, device=est.device)
     try:
@@ -847,9 +896,9 @@ def estimate_grf(estimator: CheetahEstimator, solver_output: bool = True, out_di
     if solver_output:
         print(f"Total cost: {st.cost}\n-- measurement: {st.cost_meas}\n-- energy: {ks.cost_energy}\n-- eom_error: {ks.cost_eom}\n-- torque: {ks.cost_torque}\n"
               f"status {st.status}, {st.iterations} LM iterations, {st.outer} multiplier updates, {est.opt_time_s:.3f} s\n"
-              f"max |slack_eom| {ks.max_slack:.3e} (bound {ko.slack_bound}), max violated inequality {ks.max_violation:.3e}\n"
+              f"max |slack_eom| {ks.max_slack:.3e} (box [{ko.slack_lo}, {ko.slack_hi}]), max violated inequality {ks.max_violation:.3e}\n"
               f"RMSE base: {base_err:.4f}\nRMSE links: {rel_err:.4f}")
-    ok = st.status == abi.OK and ks.max_slack <= ko.slack_bound
+    ok = st.status == abi.OK and bool((res["slack"][0] >= ko.slack_lo - 1e-4).all() and (res["slack"][0] <= ko.slack_hi + 1e-4).all())
     if ok:
         est.save("fte_grf", fname="fte", out_dir_prefix=out_dir_prefix)              # acinoset_opt.py:1045-1046
     return ok

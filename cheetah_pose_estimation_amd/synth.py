@@ -365,17 +365,21 @@ def project_dependents_numpy_hooke(sk: abi.Skeleton, q: np.ndarray) -> np.ndarra
 
 
 def make_gallop_batch(sk: abi.Skeleton, cams, B: int, N: int = 200, fps: float = 120.0, seed: int = 4321, noise_px: float = 2.0,
-                      outlier_frac: float = 0.10, init_noise: float = 0.02, dlc_thresh: float = 0.5, speed: float = 7.0):
+                      outlier_frac: float = 0.10, init_noise: float = 0.02, dlc_thresh: float = 0.5, speed: float = 7.0,
+                      kinetic_dataset: bool = False, clearance: float = 0.05, stance_frames: int = 12, x0: float = 0.0):
     """config-4 sequences: q_true, q_init (truth + noise on the independent coordinates: the physics-based solve is warm-started
-    from a kinematic solution, acinoset_opt.py:739-777), meas, weight as make_batch, and stance [B, N, 4]."""
+    from a kinematic solution, acinoset_opt.py:739-777), meas, weight as make_batch, and stance [B, N, 4].  kinetic_dataset: the 7 px
+    sigma of that data set (acinoset_misc.py:187-188); clearance: height of the swinging paws (the contact heuristic of
+    acinoset_misc.py:745-856 needs more than 5 cm to see a flight phase); x0: shift of the run along the track."""
     C, L, nq = len(cams), sk.n_markers, sk.nq
     out = dict(q_true=np.empty((B, N, nq)), q_init=np.empty((B, N, nq)), meas=np.empty((B, N, C, L, 2)), weight=np.empty((B, N, C, L)),
                stance=np.zeros((B, N, 4), np.int32))
-    sigma = measurement_sigma(L, False)
+    sigma = measurement_sigma(L, kinetic_dataset)
     ind = independent_dofs(sk)
     for b in range(B):
         rng = np.random.default_rng(seed + b)
-        qt, st = gallop_trajectory(sk, N, fps, rng, speed=speed)
+        qt, st = gallop_trajectory(sk, N, fps, rng, speed=speed, stance_frames=stance_frames, clearance=clearance)
+        qt[:, 0] += x0
         out["q_true"][b] = qt; out["stance"][b] = st
         pos, _ = fk_numpy(sk, qt)
         for c in range(C):

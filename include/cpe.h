@@ -165,10 +165,11 @@ cpe_status cpe_stream_wait(cpe_handle* h, void* other);     /* later launches of
 cpe_status cpe_stream_signal(cpe_handle* h, void* other);   /* `other` waits for the work the handle has queued so far */
 /* per-kernel device time of cpe_solve / cpe_solve_kinetic, accumulated by HIP events on the handle's stream while enabled
  * (what the reference stores as processing_time_s is one wall time around .solve(), acinoset_opt.py:610-618).
- * slots: 0 k_frame_normal, 1 k_lr_band, 2 k_lm_step, 3 k_build_act, 4 k_finalize, 5 k_dyn_term, 6 k_dyn_gather, 7 k_lm_back */
-#define CPE_PROFILE_SLOTS 8
+ * slots: 0 k_frame_normal, 1 k_lr_band, 2 k_lm_step, 3 k_build_act, 4 k_finalize, 5 k_dyn_eval, 6 k_dyn_gather, 7 k_lm_back,
+ *        8 k_dyn_assemble, 9 k_dyn_schur, 10-11 free */
+#define CPE_PROFILE_SLOTS 12
 cpe_status cpe_profile_enable(cpe_handle* h, int32_t on);                              /* also clears the totals */
-cpe_status cpe_profile_get(cpe_handle* h, double* ms /*[8]*/, int64_t* launches /*[8]*/);
+cpe_status cpe_profile_get(cpe_handle* h, double* ms /*[12]*/, int64_t* launches /*[12]*/);
 
 /* number of Jacobian slots: the structurally non-zero (marker, dof) pairs, sum_l (3 + 3*chain_len(l)), followed by 0-3
  * structurally ZERO pairs (marker 0, a dof outside its chain; the stored value is 0) that round the count up to a multiple of 4,
@@ -319,8 +320,9 @@ cpe_status cpe_eom_residual(cpe_handle* h, const cpe_dyn_options* opt, int32_t B
  * and q''_0 are free in the implicit-Euler collocation, so nodes 0 and 1 carry no dynamics), whose Gauss-Newton blocks are the
  * Schur complements of the force unknowns.  The reference's four non-negative friction components enter only through their
  * differences; the cost-neutral face is resolved by x+ x- = 0 (the minimum-norm point), i.e. net forces with |Fx| + |Fy| <= mu Fz.
- * Inequalities: augmented Lagrangian (multipliers updated with the angle bounds').  slack_bound is verified at the solution
- * (stats.max_slack), not enforced during the iteration.  motion_w of the handle's skeleton must be all zero.
+ * Inequalities: augmented Lagrangian (multipliers updated with the angle bounds'), including the box [slack_lo, slack_hi] on every
+ * component of the residual (the reference's bound_eom_error): inside the node solve its active set is iterated to a fixed point around the
+ * exact elimination, like the torque boxes'.  motion_w of the handle's skeleton must be all zero.
  * Versus the reference's `.robot` equations of motion this model is "parity unpinned" (SURVEY 8c-8): the pins are the numerical
  * Lagrangian and virtual work (tests/test_grf.py). */
 #define CPE_MAX_MOTORS 32
@@ -337,9 +339,13 @@ typedef struct cpe_kinetic_options {
     double foot_height_min;   /* 0: lower bound of `foot_height` outside stance (variable bound inside the absent pe.foot: unpinned); <= -1e9 disables */
     double ground_height;     /* Foot3D.ground_plane_height           (:500)                                                     */
     double slip_max;          /* 1: `gamma <= 1` in stance            (:803-806); <= 0 disables                                  */
-    double slack_bound;       /* 2: bound_eom_error                   (run_dataset.py:984)                                       */
+    double zvel_max;          /* 1 on the kinetic dataset, else off: `foot_z_vel <= 1` in stance (:807-810, :864-866), read as |vertical foot speed| <= zvel_max
+                               * (the variable lives in the absent pe.foot: unpinned); <= 0 disables                             */
+    double slack_lo, slack_hi;/* bound_eom_error: box on every slack_eom component, ENFORCED as augmented-Lagrangian rows on the residual:
+                               * (-2, 2) run_dataset.py:984, :1211; (-0.1, 0.1) in the last stage of run_kinetic, :1136; lo <= -1e9 and hi >= 1e9: no box */
     double reg_force;         /* Tikhonov weight on lambda and the foot forces (1e-4): picks the minimum-norm point of a face the reference leaves open */
-    double kappa_force, kappa_height, kappa_slip;     /* augmented-Lagrangian penalties (1e5, 1e6, 1e2)                          */
+    double kappa_force, kappa_height, kappa_slip;     /* augmented-Lagrangian penalties (1e5, 1e6, 1e2; kappa_slip also serves zvel_max)  */
+    double kappa_slack;       /* penalty of the slack box (1e6 = 100 w_slack)                                                    */
     double fd_step;           /* central-difference step in the reduced coordinates (1e-6)                                       */
     double lm_force_damping;  /* the node forces are eliminated from (H_ff + lambda * lm_force_damping * diag(H_ff) + walls): the trust region
                                * also acts in FORCE space, where the walls of this problem (force bounds, friction polyhedron) are */
@@ -353,14 +359,14 @@ typedef struct cpe_kinetic_stats {
     double cost_torque;       /* sum tau^2                      estimator.costs["torque"]    (acinoset_opt.py:922-928)           */
     double cost_energy;       /* sum (fps^2 second difference)^2               ["energy"]                                        */
     double cost_eom;          /* sum slack^2                                   ["eom_error"]                                     */
-    double max_slack;         /* largest |slack_eom| component (body weights), to hold against slack_bound                       */
+    double max_slack;         /* largest |slack_eom| component (body weights), to hold against [slack_lo, slack_hi]              */
     double max_base_rows;     /* largest |rows 0-2 - forces| / (M g): the reference's stored solutions have <= 8e-5 */
     double max_violation;     /* largest violated force / height / slip inequality at the solution                               */
     int32_t inner_max;        /* largest Newton iteration count of a node in the last evaluation                                 */
     int32_t _pad;
 } cpe_kinetic_stats;
 
-/* the reference's values for a given frame rate and data set (kinetic_dataset: foot_height_tol 0.03) */
+/* the reference's values for a given frame rate and data set (kinetic_dataset: foot_height_tol 0.03, zvel_max 1) */
 void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kinetic_dataset);
 
 /* Device pointers.  q_init [B][N][nq] = the kinematic solution (init_prev_kinematic_solution, acinoset_opt.py:739-777);

@@ -1106,7 +1106,8 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
 void cpo_default_kinetic_options(cpe_kinetic_options* o, double fps, int kinetic_dataset) {
     /* o->dyn (inertias, feet, motors) is the caller's */
     o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
-    o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->slack_bound = 2.0;
+    o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->zvel_max = kinetic_dataset ? 1.0 : 0.0;
+    o->slack_lo = -2.0; o->slack_hi = 2.0; o->kappa_slack = 1e6;
     o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0; o->inner_iterations = 30; o->_pad = 0;
 }
 
@@ -1123,7 +1124,7 @@ double cpo_kinetic_objective(const cpe_skeleton* s, const cpe_camera* cams, int 
     double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
     K.Mg = M * ko->dyn.eom.gravity;
     K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
-    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
+    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double)); K.mu_slack = (double*)calloc((size_t)N * CPE_MAX_NQ * 2 + 1, sizeof(double));
     K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
     K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
     x.kin = &K;
@@ -1137,7 +1138,7 @@ double cpo_kinetic_objective(const cpe_skeleton* s, const cpe_camera* cams, int 
     if (terms) { terms[0] = ct.meas; terms[1] = ct.model; terms[2] = ct.pose; terms[3] = ct.bound; terms[4] = K.torque; terms[5] = K.energy; terms[6] = K.eom; terms[7] = K.al; }
     if (g && ab) kin_add_schur(&x, N, kd, 0.0, ab);           /* exact variable-projection Gauss-Newton matrix */
     if (g && !Hband) free(ab);
-    free(st); free(K.f_cur); free(K.f_try); free(K.mu); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
+    free(st); free(K.f_cur); free(K.f_try); free(K.mu); free(K.mu_slack); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
     return ct.total;
 }
 
@@ -1153,7 +1154,7 @@ void cpo_kinetic_nodes(const cpe_skeleton* s, const cpe_camera* cams, int C, con
     double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
     K.Mg = M * ko->dyn.eom.gravity;
     K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
-    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
+    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double)); K.mu_slack = (double*)calloc((size_t)N * CPE_MAX_NQ * 2 + 1, sizeof(double));
     K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
     K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
     x.kin = &K;
@@ -1181,7 +1182,7 @@ void cpo_kinetic_nodes(const cpe_skeleton* s, const cpe_camera* cams, int C, con
         if (Hfu) for (int i = 0; i < na; i++) memcpy(Hfu + ((size_t)n * 64 + i) * nc3, K.pHfu + (size_t)n * CPE_KIN_MAXLAT * nc3 + (size_t)i * nc3, sizeof(double) * nc3);
         if (Hff) for (int i = 0; i < na; i++) for (int j = 0; j < na; j++) Hff[((size_t)n * 64 + i) * 64 + j] = K.pHff[(size_t)n * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT + (size_t)i * na + j];
     }
-    free(gT); free(HT); free(st); free(K.f_cur); free(K.f_try); free(K.mu); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
+    free(gT); free(HT); free(st); free(K.f_cur); free(K.f_try); free(K.mu); free(K.mu_slack); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
 }
 
 /* physics-based trajectory model: include/cpe.h, cpe_solve_kinetic (estimate_kinetics, acinoset_opt.py:693-963) */
@@ -1236,7 +1237,7 @@ static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* ca
     double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
     K.Mg = M * ko->dyn.eom.gravity;
     K.f_cur = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double)); K.f_try = (double*)calloc((size_t)N * K.nlat + 1, sizeof(double));
-    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double));
+    K.mu = (double*)calloc((size_t)N * K.nf * KIN_MU + 1, sizeof(double)); K.mu_slack = (double*)calloc((size_t)N * CPE_MAX_NQ * 2 + 1, sizeof(double));
     K.grf_box = grf_box; K.tau_box = tau_box; K.mu_tau = (double*)calloc((size_t)N * K.nm * 2 + 1, sizeof(double));
     K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
     K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
@@ -1259,7 +1260,7 @@ static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* ca
         kst->cost_torque = K.torque; kst->cost_energy = K.energy; kst->cost_eom = K.eom; kst->max_slack = K.max_slack;
         kst->max_base_rows = K.max_base; kst->max_violation = K.max_viol; kst->inner_max = K.inner_max; kst->_pad = 0;
     }
-    free(K.f_cur); free(K.f_try); free(K.mu); free(K.mu_tau); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
+    free(K.f_cur); free(K.f_try); free(K.mu); free(K.mu_slack); free(K.mu_tau); free(K.pHuu); free(K.pHfu); free(K.pHff); free(K.pna);
     return rc;
 }
 

@@ -123,3 +123,47 @@ def test_bound_value_is_the_reference_rule():
     assert (b[:, 0] < b[:, 1]).all()
     m = E.bound_value(np.zeros((3, 2)), 0.2)
     assert m.shape == (3, 2, 2) and np.all(m[..., 0] == -0.2) and np.all(m[..., 1] == 0.2)
+
+
+def test_force_plate_resampling_is_the_2_over_35_polyphase_filter():
+    """get_grf_profile(synthetic_data=False) (acinoset_misc.py:985-1000): remove_dc_offset(x, 500), then scipy.signal.resample_poly(up=2, down=35).
+    The product's restatement against an independent statement of that filter written out here: zero-stuff by 2, convolve with the Kaiser(5.0)
+    windowed-sinc low-pass of 2 * 10 * 35 + 1 taps (cut-off 1/35 of Nyquist of the stuffed signal, gain 2), keep every 35th sample.
+    The reference's 3.5 kHz grf/data.h5 is not shipped (and needs PyTables): synthetic table.  Versus the stored h5: parity unpinned."""
+    from scipy import signal
+    from cheetah_pose_estimation_amd import estimator as E
+    rng = np.random.default_rng(5)
+    n = 3500 * 2                                                     # two seconds of one plate
+    t = np.arange(n) / 3500.0
+    fz = 37.0 + 900.0 * np.clip(np.sin(2 * np.pi * 3.0 * (t - 0.4)), 0, None) * (t > 0.4) * (t < 0.4 + 1 / 6.0) + rng.normal(0, 2.0, n)
+    y = E.resample_force_plate(fz)
+    assert len(y) == -(-2 * n // 35) == 400                          # 200 Hz
+    x = fz - fz[:500].mean()
+    half = 10 * 35
+    taps = signal.firwin(2 * half + 1, 1.0 / 35, window=("kaiser", 5.0)) * 2.0
+    up = np.zeros(2 * n); up[::2] = x
+    full = np.convolve(up, taps)[half:half + 2 * n]                 # centred: zero phase
+    assert np.abs(y - full[::35][:len(y)]).max() < 1e-9 * np.abs(x).max()
+    # the resampled signal follows the smooth part of the plate signal: peak of the half sine, and zero before the contact
+    k = int(np.argmax(y))
+    assert abs(k / 200.0 - (0.4 + 1 / 12.0)) < 0.01 and abs(y[k] - 900.0) < 15.0 and np.abs(y[:70]).max() < 3.0
+
+
+def test_measured_plates_are_indexed_by_absolute_frame():
+    """get_grf_profile reads the resampled measured plates at Fz[start_frame + fe - 1] (acinoset_misc.py:1007-1010) and a synthetic
+    table at Fz[fe - 1] (:1003-1006): with start_frame != 0 the two conventions differ by start_frame rows"""
+    from cheetah_pose_estimation_amd import estimator as E, skeleton
+    start, N = 30, 20
+    F = np.zeros((80, 3)); F[:, 2] = np.arange(80) + 1.0; F[:, 0] = -0.1 * (np.arange(80) + 1.0)      # Fz = row + 1, Fx < 0
+    cj = {"start_frame": start, "end_frame": start + N, "contacts": {f"{skeleton.FEET[0]}_foot": [[35, 40, 1, "leading"]]}}
+    gz_rel, _ = E.grf_profile({0: F}, cj, N)
+    gz_abs, gxy_abs = E.grf_profile({0: F}, cj, N, absolute_rows=True)
+    on = np.flatnonzero(gz_rel[:, 0])
+    assert list(on) == [5, 6, 7, 8, 9, 10] == list(np.flatnonzero(gz_abs[:, 0]))
+    assert np.array_equal(gz_rel[on, 0], on + 1.0) and np.array_equal(gz_abs[on, 0], start + on + 1.0)
+    assert np.all(gxy_abs[on, 0, 2] > 0) and np.all(gxy_abs[on, 0][:, [0, 1, 3]] == 0)                    # Fx < 0: the -x side of the polygon only
+    # the raw 3.5 kHz twin goes through the resampler, direction and 1 / (M g) applied (acinoset_misc.py:985-1000)
+    raw = {0: np.tile(np.array([[10.0, -5.0, 400.0]]), (3500, 1))}
+    raw[0][:500] = 0.0                                               # unloaded plate while the DC offset is taken
+    P = E.measured_force_plates(raw, direction=-1.0, scale_forces_by=1.0 / 400.0)
+    assert P[0].shape == (200, 3) and np.abs(P[0][100] - np.array([-10.0 / 400, 5.0 / 400, 1.0])).max() < 1e-3
