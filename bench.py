@@ -287,7 +287,7 @@ def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu
     _, kst = hk.solve(T["q_init"], T["meas"], T["weight"], q, dq, ddq, pos, me)          # the kinematic estimate = the warm start
     hk.synchronize(); hk.close()
     q0 = q.clone()
-    opts = abi.default_options(120.0); opts.tol_cost, opts.max_iter = 1e-7, 600
+    opts = abi.default_options(120.0); opts.tol_cost, opts.max_iter = 1e-6, 600
     ko = abi.default_kinetic_options(skeleton.dyn_options("phantom"), 120.0)
     h = _lib.Handle(skk, cams, opts, pr_dyn, device=local)
     nm, nf, nc = ko.dyn.n_motors, ko.dyn.n_feet, h.n_constraint_rows()

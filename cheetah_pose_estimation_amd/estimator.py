@@ -767,10 +767,11 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     opts = options if options is not None else abi.default_options(scene.fps)
     opts.h = 1.0 / scene.fps
     if options is None:
-        opts.tol_cost, opts.max_iter = 1e-7, 600           # the physics term is stiff: see DESIGN.md 2b (the reference stops IPOPT at Tol = 1e-3)
+        opts.tol_cost, opts.max_iter = 1e-6, 600           # the physics term is stiff: see DESIGN.md 2b (the reference stops IPOPT at Tol = 1e-3)
     ko = kinetic_options if kinetic_options is not None else abi.default_kinetic_options(skeleton.dyn_options(est.name), scene.fps, params.kinetic_dataset)
-    if not no_slip:
-        ko.slip_max = 0.0
+    if not no_slip and not joint_estimation:
+        ko.slip_max = 0.0                                                            # `no_slip` guards the rules of the prescribed-force branch only (acinoset_opt.py:855-866);
+        ko.zvel_max = 0.0                                                            # the joint-estimation branch always has them (:803-810)
     if not joint_estimation and not ground_constraint:
         ko.foot_height_tol = 1e9                                                     # the feet are not tied to the ground (:832)
     if disable_motion_prior:
@@ -864,11 +865,12 @@ def estimate_grf(estimator: CheetahEstimator, solver_output: bool = True, out_di
     opts = options if options is not None else abi.default_options(scene.fps)
     opts.h = 1.0 / scene.fps
     if options is None:
-        opts.tol_cost, opts.max_iter = 1e-7, 600
+        opts.tol_cost, opts.max_iter = 1e-6, 600
     ko = kinetic_options if kinetic_options is not None else abi.default_kinetic_options(skeleton.dyn_options(est.name), scene.fps, True)
     if kinetic_options is None:
         ko.foot_height_tol = 0.03                                                    # foot_height in [-0.03, 0.03] during a contact (:1010-1012)
         ko.slip_max = 0.0                                                            # this NLP has no no-slip rule (estimate_kinetics adds it to ITS model)
+        ko.zvel_max = 0.0                                                            # ... and no `foot_z_vel <= 1` rule either (acinoset_opt.py:1004-1017)
     if est.bound_eom_error is not None:
         ko.slack_lo, ko.slack_hi = float(est.bound_eom_error[0]), float(est.bound_eom_error[1])      # make_pyomo_model(bound_eom_error=...), acinoset_opt.py:510-514
     skk = skeleton.without_motion_model(sk)

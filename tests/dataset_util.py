@@ -8,17 +8,18 @@ import numpy as np
 from cheetah_pose_estimation_amd import skeleton, synth
 
 
-def write_dataset(root, data_path="2019_03_07/synth/run", N=30, pad=4, seed=5, n_cams=6, noise_px=1.0, gallop=False, ppm=False, shutter_delay=None):
+def write_dataset(root, data_path="2019_03_07/synth/run", N=30, pad=4, seed=5, n_cams=6, noise_px=1.0, gallop=False, ppm=False, shutter_delay=None,
+                  clearance=0.05, speed=7.0, x_shift=6.0):
     sk = skeleton.build_skeleton("phantom", 24)
     cams = synth.make_cameras(n_cams)
     rng = np.random.default_rng(seed)
     total = N + 2 * pad
     stance = None
     if gallop:                                            # planted paws (config 4): contact windows exist to be detected
-        qt, stance = synth.gallop_trajectory(sk, total, 120.0, rng)
+        qt, stance = synth.gallop_trajectory(sk, total, 120.0, rng, clearance=clearance, speed=speed)
     else:
         qt = synth.truth_trajectory(sk, total, 120.0, rng)
-    qt[:, 0] += 6.0                                       # mid-track: every camera sees the animal
+    qt[:, 0] += x_shift                                   # mid-track: every camera sees the animal
     pos, _ = synth.fk_numpy(sk, qt)
     ddir = os.path.join(root, data_path)
     os.makedirs(os.path.join(ddir, "dlc"), exist_ok=True)

@@ -109,7 +109,7 @@ def test_short_solve_respects_the_contact_rules(oracle):
     (|rows 0-2| / Mg <= 8e-5 x a few), forces inside their bounds and the friction polyhedron, planted paws near the ground"""
     sk, cams, opts, ko, d = _problem(12, n_cams=6, init_noise=0.02)
     kin = oracle.solve(skeleton.build_skeleton("phantom", 24), cams, opts, None, d["q_init"][0], d["meas"][0], d["weight"][0])
-    opts.tol_cost, opts.max_iter = 1e-7, 400
+    opts.tol_cost, opts.max_iter = 1e-6, 400
     r = oracle.solve_kinetic(sk, cams, opts, None, ko, kin["q"], d["meas"][0], d["weight"][0], d["stance"][0])
     st, ks = r["stats"], r["kstats"]
     assert r["status"] == abi.OK and st.iterations < 400
