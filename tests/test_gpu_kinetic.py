@@ -397,7 +397,7 @@ def test_monocular_physics_with_pose_prior_and_detected_contacts(oracle, gpu_han
     assert st.outer == so.outer and abs(st.iterations - so.iterations) <= max(2, so.iterations // 5)
     assert rmse < 1e-3, rmse
     # (a flat valley: the two stop a few iterations apart; the pose term is a negative log-likelihood of a density, it may be negative)
-    assert abs(st.cost - so.cost) < 1e-3 * abs(so.cost) and st.cost_pose != 0.0 and abs(st.cost_pose - so.cost_pose) < 1e-3 * abs(so.cost_pose)
+    assert abs(st.cost - so.cost) < 1e-3 * abs(so.cost) and st.cost_pose != 0.0 and abs(st.cost_pose - so.cost_pose) < 5e-3 * abs(so.cost_pose)
     assert np.sqrt(((r["positions"][0] - truth) ** 2).sum(-1).mean()) < np.sqrt(((kin["positions"][0] - truth) ** 2).sum(-1).mean())      # the physics helps
     assert ks.max_slack < ko.slack_hi and ks.max_violation < 1e-3 and abs(ks.cost_torque - kso.cost_torque) < 1e-2 * kso.cost_torque
     g = r["grf"][0]
