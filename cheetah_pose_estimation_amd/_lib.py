@@ -162,7 +162,7 @@ class Handle:
         _check(self.lib.cpe_stream_signal(self._h, self._torch_stream()), "cpe_stream_signal")
 
     PROFILE_SLOTS = ("k_frame_normal", "k_lr_band", "k_lm_step", "k_build_act", "k_finalize", "k_dyn_eval", "k_dyn_gather", "k_lm_back",
-                     "k_dyn_assemble", "k_dyn_schur", "_free10", "_free11")
+                     "k_dyn_assemble", "k_dyn_schur", "k_dyn_jac", "_free11")
 
     def profile(self, on: bool):
         _check(self.lib.cpe_profile_enable(self._h, 1 if on else 0), "cpe_profile_enable")

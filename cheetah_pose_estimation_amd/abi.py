@@ -110,7 +110,7 @@ class KineticOptions(C.Structure):
                 ("force_max", C.c_double), ("grfz_min", C.c_double), ("foot_height_tol", C.c_double), ("foot_height_min", C.c_double),
                 ("ground_height", C.c_double), ("slip_max", C.c_double), ("zvel_max", C.c_double), ("slack_lo", C.c_double), ("slack_hi", C.c_double),
                 ("reg_force", C.c_double), ("kappa_force", C.c_double), ("kappa_height", C.c_double), ("kappa_slip", C.c_double), ("kappa_slack", C.c_double),
-                ("fd_step", C.c_double),
+
                 ("lm_force_damping", C.c_double), ("lm_wall_damping", C.c_double), ("inner_iterations", C.c_int32), ("_pad", C.c_int32)]
 
 
@@ -131,7 +131,7 @@ def default_kinetic_options(dyn: DynOptions, fps: float = 120.0, kinetic_dataset
     o.foot_height_min, o.ground_height, o.slip_max = 0.0, 0.0, 1.0
     o.zvel_max = 1.0 if kinetic_dataset else 0.0       # `foot_z_vel <= 1` is a rule of the kinetic dataset only (acinoset_opt.py:807-810)
     o.slack_lo, o.slack_hi = -2.0, 2.0                 # bound_eom_error of run_dataset.py:984
-    o.reg_force, o.kappa_force, o.kappa_height, o.kappa_slip, o.kappa_slack, o.fd_step = 1e-4, 1e5, 1e6, 1e2, 1e6, 1e-6
+    o.reg_force, o.kappa_force, o.kappa_height, o.kappa_slip, o.kappa_slack = 1e-4, 1e5, 1e6, 1e2, 1e6
     o.lm_force_damping, o.lm_wall_damping = 10.0, 10.0
     o.inner_iterations = 30
     return o

@@ -1054,7 +1054,7 @@ void cpe_default_kinetic_options(cpe_kinetic_options* o, double fps, int32_t kin
     o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
     o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->zvel_max = kinetic_dataset ? 1.0 : 0.0;
     o->slack_lo = -2.0; o->slack_hi = 2.0; o->kappa_slack = 1e6;
-    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0;
+    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0;
     o->inner_iterations = 30; o->_pad = 0;
 }
 
@@ -1069,9 +1069,9 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
     for (int k = 0; k < d.n_motors; k++)
         if (d.motor_first[k] < 0 || d.motor_first[k] >= m.nl || d.motor_second[k] < 0 || d.motor_second[k] >= m.nl || d.motor_axis[k] < 0 || d.motor_axis[k] > 2)
             return fail(CPE_BAD_ARG, "motor definition out of range");
-    if (!(opt->w_slack > 0) || !(opt->kappa_force > 0) || !(opt->kappa_height > 0) || !(opt->kappa_slip > 0) || !(opt->fd_step > 0) || !(opt->reg_force > 0) ||
+    if (!(opt->w_slack > 0) || !(opt->kappa_force > 0) || !(opt->kappa_height > 0) || !(opt->kappa_slip > 0) || !(opt->reg_force > 0) ||
         !(d.eom.gravity > 0) || opt->inner_iterations < 1)
-        return fail(CPE_BAD_ARG, "kinetic options: weights, penalties, step and gravity must be positive");
+        return fail(CPE_BAD_ARG, "kinetic options: weights, penalties and gravity must be positive");
     for (int k = 0; k < m.nu; k++) if (m.motion_w_u[k] != 0.0) return fail(CPE_BAD_ARG, "the physics-based model replaces the constant-acceleration cost: motion_w must be zero");
     if (h->lr_window > 0) return fail(CPE_BAD_ARG, "the physics-based model does not use the autoregressive motion prior (acinoset_opt.py:905-921)");
     K.nm = d.n_motors; K.nf = d.n_feet; K.nc = 0;
@@ -1090,6 +1090,42 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
     K.grf_fix = grf_fix;
     K.grf_box = grf_box;
     K.tau_box = tau_box; K.mu_tau = h->kmut;            // (the workspace is sized before this is called)
+    // ---- tables of the analytic Jacobian (k_dyn_jac): ancestry of the link pairs, moments of every subtree about its link's origin
+    {
+        const int nl = m.nl;
+        auto is_anc = [&](int a, int i) { int j = m.parent[i]; while (j >= 0) { if (j == a) return true; j = m.parent[j]; } return false; };      // a strict ancestor of i
+        auto toward = [&](int up, int down) { int j = down; while (m.parent[j] != up) j = m.parent[j]; return j; };                                 // child of `up` on the path to `down`
+        K.nblk = 0;
+        for (int i = 0; i < nl; i++) for (int k = 0; k < nl; k++) {
+            int rel = 0, tw = 0;
+            if (i == k) rel = 3;
+            else if (is_anc(k, i)) { rel = 1; tw = toward(k, i); }
+            else if (is_anc(i, k)) { rel = 2; tw = toward(i, k); }
+            K.rel[i][k] = (int8_t)rel; K.toward[i][k] = (int8_t)tw; K.blk[i][k] = -1;
+            if (rel) {
+                if (K.nblk >= 96) return fail(CPE_BAD_ARG, "skeleton too deep for the kinetic kernels (more than 96 related link pairs)");
+                K.blk[i][k] = (int16_t)K.nblk; K.blk_i[K.nblk] = (int8_t)i; K.blk_k[K.nblk] = (int8_t)k; K.nblk++;
+            }
+        }
+        std::vector<double> msub(nl, 0.0);
+        for (int i = 0; i < nl; i++) for (int j = 0; j < nl; j++) if (j == i || is_anc(i, j)) msub[i] += m.mass[j];
+        K.mtot = mt;
+        for (int i = 0; i < nl; i++) {
+            for (int d = 0; d < 3; d++) K.s1[i][d] = m.mass[i] * m.com[i][d];
+            for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) K.S2[i][3 * a + b2] = m.mass[i] * m.com[i][a] * m.com[i][b2];
+            for (int c = 0; c < nl; c++) if (m.parent[c] == i) {
+                for (int d = 0; d < 3; d++) K.s1[i][d] += msub[c] * m.attach[c][d];
+                for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) K.S2[i][3 * a + b2] += msub[c] * m.attach[c][a] * m.attach[c][b2];
+            }
+            K.leg_of_link[i] = -1; K.hooke_of_link[i] = -1;
+        }
+        for (int r = 0; r < m.nrev; r++) K.leg_of_link[m.rev_child[r]] = (int8_t)r;
+        K.nh = 0;
+        for (int j = 0; j < m.nj; j++) if (m.joint_kind[j] == CPE_JOINT_HOOKE_YZ) {          // joints are stored parents first (cpe_model.h)
+            if (K.nh >= 4) return fail(CPE_BAD_ARG, "more than four Hooke joints");
+            K.hk_parent[K.nh] = (int8_t)m.joint_parent[j]; K.hk_child[K.nh] = (int8_t)m.joint_child[j]; K.hooke_of_link[m.joint_child[j]] = (int8_t)K.nh; K.nh++;
+        }
+    }
     K.mu_slack = h->kmus; K.sbox = (opt->slack_hi < 1e9 || opt->slack_lo > -1e9) ? 1 : 0;
     if (K.sbox && (!(opt->kappa_slack > 0) || !(opt->slack_lo < opt->slack_hi))) return fail(CPE_BAD_ARG, "kinetic options: slack box needs lo < hi and a positive penalty");
     if (!h->dk) HIPCHK(hipMalloc(&h->dk, sizeof(DevKin)));
@@ -1124,7 +1160,7 @@ static cpe_status ensure_kws(cpe_handle* h, int B, int N) {
     HIPCHK(hipMalloc(&h->gk, sizeof(double) * F * CPE_NX));
     HIPCHK(hipMalloc(&h->Bk, sizeof(double) * F * BB));
     HIPCHK(hipMalloc(&h->Hk, sizeof(double) * F * 3 * BB));
-    const void* ks[] = {(const void*)&k_dyn_eval, (const void*)&k_dyn_assemble, (const void*)&k_dyn_schur};
+    const void* ks[] = {(const void*)&k_dyn_eval, (const void*)&k_dyn_assemble, (const void*)&k_dyn_schur, (const void*)&k_dyn_jac};
     for (const void* k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     h->kws_frames = F;
     return CPE_OK;
@@ -1136,6 +1172,9 @@ static void launch_dyn_eval(cpe_handle* h, int N, int first, size_t Fw, const in
     prof_begin(h, 5);
     hipLaunchKernelGGL(k_dyn_eval, dim3(gf), dim3(KIN_THREADS), lds_kin_eval(), h->stream, h->dm, h->dk, h->st, N, first, Fw, h->qbuf, stance, h->fbuf, h->kmu, h->costbuf,
                        h->Jbuf, h->Abuf, h->pieces, h->pmeta, h->dstat, h->slackb, act, n_act);
+    prof_end(h);
+    prof_begin(h, 10);
+    hipLaunchKernelGGL(k_dyn_jac, dim3(gf), dim3(KJ_THREADS), sizeof(double) * KJ_DOUBLES, h->stream, h->dm, h->dk, h->st, N, first, Fw, h->qbuf, h->fbuf, h->Jbuf, act, n_act);
     prof_end(h);
     prof_begin(h, 8);
     hipLaunchKernelGGL(k_dyn_assemble, dim3(gf), dim3(KIN_THREADS), lds_kin_assemble(), h->stream, h->dm, h->dk, h->st, N, first, Fw, h->Jbuf, h->Abuf, h->pieces, h->pmeta,
@@ -1354,6 +1393,12 @@ cpe_status cpe_debug_footprint(const cpe_skeleton* skel, const cpe_camera* cams,
     const DevModel& m = mv[0];
     const int64_t v[16] = {m.nq, m.ns, m.nu, m.ndep, m.nrev, m.S, m.ss_n, m.sv_n, m.mc_total, (int64_t)lds_normal(m), (int64_t)sizeof(DevModel), m.L, m.C, m.nl, m.nb, 0};
     for (int i = 0; i < 16; i++) out16[i] = v[i];
+    return CPE_OK;
+}
+// diagnostic build only: the Jacobian of the rows of frame `frame` of the last cpe_eval_kinetic_nodes / solve, column-major [84][KIN_ROWS_MAX] + row gradient + row weight
+cpe_status cpe_debug_kinetic_jacobian(cpe_handle* h, int64_t frame, double* out) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->Jbuf + (size_t)frame * KIN_JSTRIDE, sizeof(double) * KIN_JSTRIDE, hipMemcpyDeviceToHost));
     return CPE_OK;
 }
 cpe_status cpe_debug_fn_stamps(unsigned long long* out16) {

@@ -564,3 +564,4 @@ __global__ __launch_bounds__(WAVE) void k_project(const DevModel* __restrict__ M
 
 #include "cpe_solver.hip.inc"
 #include "cpe_kinetic.hip.inc"
+#include "cpe_kinetic_jac.hip.inc"

@@ -166,7 +166,7 @@ cpe_status cpe_stream_signal(cpe_handle* h, void* other);   /* `other` waits for
 /* per-kernel device time of cpe_solve / cpe_solve_kinetic, accumulated by HIP events on the handle's stream while enabled
  * (what the reference stores as processing_time_s is one wall time around .solve(), acinoset_opt.py:610-618).
  * slots: 0 k_frame_normal, 1 k_lr_band, 2 k_lm_step, 3 k_build_act, 4 k_finalize, 5 k_dyn_eval, 6 k_dyn_gather, 7 k_lm_back,
- *        8 k_dyn_assemble, 9 k_dyn_schur, 10-11 free */
+ *        8 k_dyn_assemble, 9 k_dyn_schur, 10 k_dyn_jac, 11 free */
 #define CPE_PROFILE_SLOTS 12
 cpe_status cpe_profile_enable(cpe_handle* h, int32_t on);                              /* also clears the totals */
 cpe_status cpe_profile_get(cpe_handle* h, double* ms /*[12]*/, int64_t* launches /*[12]*/);
@@ -346,7 +346,6 @@ typedef struct cpe_kinetic_options {
     double reg_force;         /* Tikhonov weight on lambda and the foot forces (1e-4): picks the minimum-norm point of a face the reference leaves open */
     double kappa_force, kappa_height, kappa_slip;     /* augmented-Lagrangian penalties (1e5, 1e6, 1e2; kappa_slip also serves zvel_max)  */
     double kappa_slack;       /* penalty of the slack box (1e6 = 100 w_slack)                                                    */
-    double fd_step;           /* central-difference step in the reduced coordinates (1e-6)                                       */
     double lm_force_damping;  /* the node forces are eliminated from (H_ff + lambda * lm_force_damping * diag(H_ff) + walls): the trust region
                                * also acts in FORCE space, where the walls of this problem (force bounds, friction polyhedron) are */
     double lm_wall_damping;   /* walls: + lambda * lm_wall_damping * 2 w_slack * sum over the INACTIVE force inequalities c c^T / gap^2

@@ -1103,12 +1103,17 @@ cpe_status cpo_solve(const cpe_skeleton* s, const cpe_camera* cams, int C, const
     return solve_impl(s, cams, C, o, pr, N, q_init, meas, weight, q, dq, ddq, positions, meas_err, st, NULL);
 }
 
+/* tests: cpo_kinetic_nodes also copies the Jacobian [nrow][84] of node `node` to J (NULL switches it off); numeric: fourth-order differences instead of the closed form */
+static double* g_dbgJ = NULL; static int g_dbgJ_node = -1, g_numeric_jacobian = 0;
+void cpo_set_debug_jacobian(double* J, int node) { g_dbgJ = J; g_dbgJ_node = node; }
+void cpo_set_numeric_jacobian(int on) { g_numeric_jacobian = on; }      /* applies to every later cpo_kinetic_* / cpo_solve_kinetic* call */
+
 void cpo_default_kinetic_options(cpe_kinetic_options* o, double fps, int kinetic_dataset) {
     /* o->dyn (inertias, feet, motors) is the caller's */
     o->w_slack = 10e3; o->w_torque = 1.0; o->w_smooth = 0.1 / (fps * fps); o->friction = 0.8; o->force_max = 5.0; o->grfz_min = 0.01;
     o->foot_height_tol = kinetic_dataset ? 0.03 : 0.1; o->foot_height_min = 0.0; o->ground_height = 0.0; o->slip_max = 1.0; o->zvel_max = kinetic_dataset ? 1.0 : 0.0;
     o->slack_lo = -2.0; o->slack_hi = 2.0; o->kappa_slack = 1e6;
-    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->fd_step = 1e-6; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0; o->inner_iterations = 30; o->_pad = 0;
+    o->reg_force = 1e-4; o->kappa_force = 1e5; o->kappa_height = 1e6; o->kappa_slip = 1e2; o->lm_force_damping = 10.0; o->lm_wall_damping = 10.0; o->inner_iterations = 30; o->_pad = 0;
 }
 
 /* objective of the physics-based model at a point (multipliers zero), its reduced gradient and, optionally, the band matrix:
@@ -1118,7 +1123,7 @@ double cpo_kinetic_objective(const cpe_skeleton* s, const cpe_camera* cams, int 
                              double* g /*[N*nu] or NULL*/, double* Hband /*[N*nu][4 nu] or NULL*/, double* terms /*[8] or NULL*/) {
     ctx_t x; ctx_init(&x, s, cams, C, o, pr);
     kin_t K; memset(&K, 0, sizeof(K));
-    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h;
+    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h; K.numeric_jacobian = g_numeric_jacobian;
     for (int j = 0; j < s->n_joints; j++) K.nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
     K.nlat = K.nm + K.nc + 3 * K.nf;
     double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
@@ -1142,13 +1147,14 @@ double cpo_kinetic_objective(const cpe_skeleton* s, const cpe_camera* cams, int 
     return ct.total;
 }
 
+
 /* per-node quantities of one evaluation of the physics terms (multipliers zero, cold start), in cpe_eval_kinetic_nodes' layout:
  * f [N][64], stat [N][8], g [N][84], Huu [N][84][84], Hfu [N][64][84], Hff [N][64][64], meta [N][65] */
 void cpo_kinetic_nodes(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o, const cpe_kinetic_options* ko, int N,
                        const double* q, const int32_t* stance, double* f, double* stat, double* g, double* Huu, double* Hfu, double* Hff, int32_t* meta) {
     ctx_t x; ctx_init(&x, s, cams, C, o, NULL);
     kin_t K; memset(&K, 0, sizeof(K));
-    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h;
+    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h; K.numeric_jacobian = g_numeric_jacobian;
     for (int j = 0; j < s->n_joints; j++) K.nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
     K.nlat = K.nm + K.nc + 3 * K.nf;
     double M = 0; for (int i = 0; i < s->n_links; i++) M += s->mass[i];
@@ -1158,6 +1164,7 @@ void cpo_kinetic_nodes(const cpe_skeleton* s, const cpe_camera* cams, int C, con
     K.pHuu = (double*)malloc(sizeof(double) * (size_t)N * KIN_NC3 * KIN_NC3); K.pHfu = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * KIN_NC3);
     K.pHff = (double*)malloc(sizeof(double) * (size_t)N * CPE_KIN_MAXLAT * CPE_KIN_MAXLAT); K.pna = (int*)calloc(N + 1, sizeof(int));
     x.kin = &K;
+    K.dbgJ = g_dbgJ; K.dbgJ_node = g_dbgJ_node;
     double* st = (double*)malloc(sizeof(double) * (size_t)N * x.ns);
     for (int n = 0; n < N; n++) state_from_q(&x, q + (size_t)n * x.nq, st + (size_t)n * x.ns);
     int nc3 = KIN_NC3;
@@ -1230,7 +1237,7 @@ static cpe_status solve_kinetic_impl(const cpe_skeleton* s, const cpe_camera* ca
     int nq = NQ(s);
     for (int p = 0; p < nq; p++) if (s->motion_w[p] != 0.0) return CPE_BAD_ARG;      /* the physics replaces the constant-acceleration cost */
     kin_t K; memset(&K, 0, sizeof(K));
-    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h; K.grf_fix = grf_fixed;
+    K.ko = ko; K.stance = stance; K.N = N; K.nm = ko->dyn.n_motors; K.nf = ko->dyn.n_feet; K.h = o->h; K.numeric_jacobian = g_numeric_jacobian; K.grf_fix = grf_fixed;
     for (int j = 0; j < s->n_joints; j++) K.nc += s->joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 2 : 1;
     K.nlat = K.nm + K.nc + 3 * K.nf;
     if (K.nlat > CPE_KIN_MAXLAT) return CPE_BAD_ARG;

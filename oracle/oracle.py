@@ -134,15 +134,28 @@ def kinetic_objective(sk, cams, opts, priors, kopts, q, meas, weight, stance, wa
     return float(f), g, q, terms, band
 
 
-def kinetic_nodes(sk, cams, opts, kopts, q, stance):
-    """per-node quantities of one evaluation of the physics terms, in cpe_eval_kinetic_nodes' layout (dict of arrays)"""
+def set_numeric_jacobian(on: bool):
+    """physics-based model: differentiate the node rows numerically (fourth-order differences) instead of in closed form, until switched back"""
+    lib().cpo_set_numeric_jacobian(1 if on else 0)
+
+
+def kinetic_nodes(sk, cams, opts, kopts, q, stance, jac_node=None):
+    """per-node quantities of one evaluation of the physics terms, in cpe_eval_kinetic_nodes' layout (dict of arrays); jac_node: also the
+    numerical Jacobian [nrow, 84] of that node's rows (out["J"])"""
     q = _c(q); stance = np.ascontiguousarray(stance, dtype=np.int32)
     N = q.shape[0]
+    Jd = None
+    if jac_node is not None:
+        Jd = np.zeros((sk.nq + 4 * kopts.dyn.n_feet + 3 * sk.n_markers, 84))
+        lib().cpo_set_debug_jacobian(_p(Jd), int(jac_node))
     out = dict(f=np.zeros((N, 64)), stat=np.zeros((N, 8)), g=np.zeros((N, 84)), Huu=np.zeros((N, 84, 84)), Hfu=np.zeros((N, 64, 84)),
                Hff=np.zeros((N, 64, 64)), meta=np.zeros((N, 65), dtype=np.int32))
     lib().cpo_kinetic_nodes(C.byref(sk), cams, len(cams), C.byref(opts), C.byref(kopts), N, _p(q), stance.ctypes.data_as(C.POINTER(C.c_int32)),
                             _p(out["f"]), _p(out["stat"]), _p(out["g"]), _p(out["Huu"]), _p(out["Hfu"]), _p(out["Hff"]),
                             out["meta"].ctypes.data_as(C.POINTER(C.c_int32)))
+    if Jd is not None:
+        lib().cpo_set_debug_jacobian(None, -1)
+        out["J"] = Jd
     return out
 
 

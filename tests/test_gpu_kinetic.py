@@ -25,6 +25,9 @@ def test_node_terms_match_oracle(oracle, gpu_handle_factory):
     opts = abi.default_options(120.0)
     d = synth.make_gallop_batch(sk, cams, B=2, N=14, seed=4321, init_noise=0.002)
     h = gpu_handle_factory(sk, cams, opts)
+    # sequence 1: two hock links of frame 6 next to the pole of their Euler chart (the nearest-triple rule shifts them along phi -+ psi = const)
+    from test_kinetic_oracle import _near_pole_sequence
+    d["q_init"][1] = _near_pole_sequence(oracle, sk, {"q_init": d["q_init"][1:2]})
     G = h.eval_kinetic_nodes_host(ko, d["q_init"], d["meas"], d["weight"], d["stance"])
     for b in range(2):
         R = oracle.kinetic_nodes(sk, cams, opts, ko, d["q_init"][b], d["stance"][b])
@@ -394,7 +397,7 @@ def test_monocular_physics_with_pose_prior_and_detected_contacts(oracle, gpu_han
     assert st.status == ro["status"] and st.status in (abi.OK, abi.MAX_ITER)
     # ~150 iterations along a flat floor (one camera: the depth direction is held by the priors and the physics only); the two implementations
     # stop within a fifth of each other's count, at the same number of multiplier updates; the statement is on the end point
-    assert st.outer == so.outer and abs(st.iterations - so.iterations) <= max(2, so.iterations // 5)
+    assert st.outer == so.outer and abs(st.iterations - so.iterations) <= max(2, so.iterations // 20)
     assert rmse < 1e-3, rmse
     # (a flat valley: the two stop a few iterations apart; the pose term is a negative log-likelihood of a density, it may be negative)
     assert abs(st.cost - so.cost) < 1e-3 * abs(so.cost) and st.cost_pose != 0.0 and abs(st.cost_pose - so.cost_pose) < 5e-3 * abs(so.cost_pose)

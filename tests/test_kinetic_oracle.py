@@ -291,3 +291,40 @@ def test_vertical_foot_speed_rule_of_the_kinetic_dataset(oracle):
     assert r["status"] in (abi.OK, abi.MAX_ITER)
     assert np.abs(vz(r))[on].max() < 0.25 * v0 * (1 + 1e-2) + 1e-3 and r["kstats"].max_violation < 1e-4
     assert r["stats"].cost >= free["stats"].cost * (1 - 1e-9)
+
+
+def _near_pole_sequence(oracle, sk, d):
+    """the test gallop with two hock links of frame 6 moved next to the pole of their Euler chart (pitch -90 deg): one inside the fully shifted zone
+    (|cos theta| < KIN_POLE / 2 = 0.05), one inside the blending zone -- nodes 6, 7 and 8 then difference angles across the pole"""
+    q = d["q_init"][0].copy()
+    ind = list(skeleton.independent_dofs(sk))
+    for link, target in (("HFL", -np.pi / 2 + 0.03), ("HBR", -np.pi / 2 + 0.08)):
+        p = skeleton.dof(link, skeleton.THETA)
+        q = oracle.move_coordinate(sk, q, 6, ind.index(p), target - q[6, p])
+        q = oracle.move_coordinate(sk, q, 6, ind.index(p), target - q[6, p])          # (the leg angle moves the pitch one to one up to the body's roll)
+    assert abs(np.cos(q[6, skeleton.dof("HFL", skeleton.THETA)])) < 0.05 and 0.05 < abs(np.cos(q[6, skeleton.dof("HBR", skeleton.THETA)])) < 0.1
+    return q
+
+
+def test_closed_form_jacobian_equals_the_numerical_one(oracle):
+    """the rows of a node are differentiated in closed form (HIP: csrc/cpe_kinetic_jac.hip.inc; here: the dense restatement
+    kin_jacobian_closed_form) -- subtree moments, second time derivatives of the link rotations, the coordinate map, the nearest-triple rule with
+    its pole blocks.  Checked against fourth-order central differences of the whole row evaluation THROUGH the coordinate map, row group by row
+    group, on ordinary nodes and on nodes whose frames straddle the pole of a leg link's Euler chart."""
+    sk, cams, opts, ko, d = _problem(14)
+    ko.zvel_max = 1.0
+    stn = d["stance"][0]
+    for q, nodes in ((d["q_init"][0], (5, 9)), (_near_pole_sequence(oracle, sk, d), (6, 7, 8))):
+        for node in nodes:
+            A = oracle.kinetic_nodes(sk, cams, opts, ko, q, stn, jac_node=node)
+            oracle.set_numeric_jacobian(True)
+            try:
+                Nn = oracle.kinetic_nodes(sk, cams, opts, ko, q, stn, jac_node=node)
+            finally:
+                oracle.set_numeric_jacobian(False)
+            Ja, Jn = A["J"], Nn["J"]
+            for lo, hi, name in ((0, 3, "force balance"), (3, 54, "angle rows"), (54, 58, "foot height"), (58, 70, "foot velocity"), (70, 142, "second differences")):
+                scale = np.abs(Jn[lo:hi]).max()
+                assert np.abs(Ja[lo:hi] - Jn[lo:hi]).max() < 2e-8 * scale, (node, name, np.abs(Ja[lo:hi] - Jn[lo:hi]).max() / scale)
+            for key in ("g", "Huu", "Hfu"):
+                assert np.abs(A[key] - Nn[key]).max() < 1e-9 * np.abs(Nn[key]).max(), (node, key)
