@@ -264,7 +264,10 @@ def kinetic_flops_per_node(nq=54, nrow=138, nlat=60, nc3=84, nx=48):
     jtj = nrow * nc3 * nc3
     afj = 2 * nq * nlat * nc3
     schur = nlat * nlat * nc3 + nlat * nc3 * nc3
-    return dict(k_dyn_eval=gram + chol, k_dyn_assemble=jtj + afj, k_dyn_schur=schur + nlat ** 3 / 3.0)
+    # closed-form Jacobian: three block matrices over the 89 related link pairs (~60 flops an entry), then 84 columns x (54 rows x <= 9 touched
+    # links x 27 + 88 marker rows x ~40) multiply-adds
+    jac = 2.0 * (3 * 89 * 9 * 60 + nc3 * (nq * 5 * 27 + (nrow - nq) * 40))
+    return dict(k_dyn_eval=gram + chol, k_dyn_jac=jac, k_dyn_assemble=jtj + afj, k_dyn_schur=schur + nlat ** 3 / 3.0)
 
 
 def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu=True):
@@ -305,20 +308,21 @@ def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu
     wni = float((np.array([s_.iterations for s_ in wstats]) + 1).sum()) * (N - 2)    # node-iterations of the profiled run
     nrow, nlat, nc3, nq = sk.nq + 3 * nf + 3 * 24, nm + nc + 3 * nf, 84, sk.nq
     KP = nc3 * nc3 + 64 * nc3 + 64 * 64
-    byts = dict(k_dyn_eval=8 * (3 * 66 + 64 + 68 + nrow * nc3 + 2 * nrow + nq * 64 + 64 * 64 + 64 + 8 + nq),      # states, warm start, multipliers in; J, row gradient / weight, A, H_ff, forces, record, slack out
+    byts = dict(k_dyn_eval=8 * (3 * 66 + 64 + 76 + 2 * nq + 2 * nrow + nq * 64 + 64 * 64 + 64 + 8 + nq),      # states, warm start, multipliers in; row gradient / weight, A, H_ff, forces, record, slack out
+                k_dyn_jac=8 * (3 * 66 + 64 + nrow * nc3),                                                       # states, forces in; J out
                 k_dyn_assemble=8 * (nrow * nc3 + 2 * nrow + nq * 64 + nc3 * nc3 + 64 * nc3 + nc3),                 # J, A in; H_uu, H_fu, gradient out
                 k_dyn_schur=8 * (KP + 64 + 68 + 6 * 28 * 28),                                                       # the three pieces in; six blocks out
                 k_dyn_gather=8 * (3 * 6 * 28 * 28 + 28 * 28 + 3 * nc3 + 28 + 28 * 28 + 3 * 28 * 28 + 28))           # three nodes' blocks in; band blocks + gradient out
     fl = kinetic_flops_per_node(nq, nrow, nlat, nc3, nm + nc)
     ms = {k: v[0] for k, v in prof.items()}; nl = {k: v[1] for k, v in prof.items()}
     kern = {}
-    for k in ("k_dyn_eval", "k_dyn_assemble", "k_dyn_schur", "k_dyn_gather"):
+    for k in ("k_dyn_eval", "k_dyn_jac", "k_dyn_assemble", "k_dyn_schur", "k_dyn_gather"):
         kern[k] = dict(ms_total=ms.get(k, 0.0), launches=nl.get(k, 0), bytes_per_node_iteration=byts[k], roofline=roof_bytes(byts[k] * wni, ms.get(k, 0.0)),
                        fp64=roof_flops(fl[k] * wni, ms.get(k, 0.0)) if k in fl else None)
     for k in ("k_frame_normal", "k_lm_step", "k_lm_back"):
         kern[k] = dict(ms_total=ms.get(k, 0.0), launches=nl.get(k, 0))
     tot = sum(v["ms_total"] for v in kern.values())
-    dom = max(("k_dyn_eval", "k_dyn_assemble", "k_dyn_schur", "k_dyn_gather"), key=lambda k: kern[k]["ms_total"])
+    dom = max(("k_dyn_eval", "k_dyn_jac", "k_dyn_assemble", "k_dyn_schur", "k_dyn_gather"), key=lambda k: kern[k]["ms_total"])
     out = dict(value=B / el, unit="solves/s", workload=f"cfg4: physics-based model, 200 frames x {n_cams} camera(s) x 24 markers, rotary gallop 3 Hz, 12-frame stance, seed 4321 + b"
                + (", pose prior, monocular warm start" if n_cams == 1 else ""),
                batch=B, seconds=el, iterations_mean=float(its.mean()), iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()),
@@ -395,7 +399,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10, help="untimed launches; the clocks of an idle MI355X need ~10 launches (30 ms) to ramp")
     ap.add_argument("--batch", type=int, default=2048, help="sequences per GPU for the residual+Jacobian pass")
-    ap.add_argument("--solve-batch", type=int, default=2048, help="sequences per GPU for the solve timing")
+    ap.add_argument("--solve-batch", type=int, default=8192, help="sequences per GPU for the solve timing (8 MB of solver workspace each: 64 GB of the 288 GB)")
     ap.add_argument("--markers", type=int, default=25)
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true")
@@ -403,7 +407,7 @@ def main():
     ap.add_argument("--no-l24", action="store_true", help="skip the extra 24-marker residual+Jacobian measurement")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 (monocular + learned priors) and config-4 (physics-based) solve timings")
     ap.add_argument("--cfg3-batch", type=int, default=256)
-    ap.add_argument("--cfg4-batch", type=int, default=16)
+    ap.add_argument("--cfg4-batch", type=int, default=64)
     ap.add_argument("--cfg4-cams", type=int, default=6, choices=(1, 6), help="cameras of the physics-based timing (1 = monocular + pose prior, as the reference runs it)")
     args = ap.parse_args()
 
@@ -582,7 +586,16 @@ def main():
                                 "frac": (fn_b + lm_b) * frame_its / el / HBM_PEAK},
                 "note": "latency-bound (200 sequential block columns x 28 pivots per sequence, two 80 KB workgroups per CU): far from both rooflines, see DESIGN.md 6"}
         solves = dict(value=world * Bs / el, unit="solves/s", batch_per_gpu=Bs, seconds=el, iterations_mean=float(its.mean()),
-                      iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()), roofline=roof)
+                      iterations_max=int(its.max()), iterations_p99=float(np.percentile(its, 99)), converged_frac=float((stt == 0).mean()), roofline=roof)
+        if world == 1 and Bs > 2048:
+            # the batch size of rounds 1-2, for continuity: with one seed per sequence the slowest of 2048 (93 iterations against 22 on average) leaves
+            # the launches half empty for a third of the run; the larger batch above amortises that drain
+            t2_ = time.perf_counter()
+            _, st2 = h.solve(ts_["q_init"][:2048], ts_["meas"][:2048], ts_["weight"][:2048], q[:2048], dq[:2048], ddq[:2048], pos[:2048], me[:2048])
+            h.synchronize()
+            e2 = time.perf_counter() - t2_
+            i2 = np.array([s_.iterations for s_ in st2])
+            solves["batch_2048"] = dict(value=2048 / e2, seconds=e2, iterations_mean=float(i2.mean()), iterations_max=int(i2.max()))
         if world == 1:
             # latency of ONE sequence through the drop-in path's solver (B = 1: one workgroup on one CU), N = 200 and N = 57
             lat = {}

@@ -1126,6 +1126,7 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
             K.hk_parent[K.nh] = (int8_t)m.joint_parent[j]; K.hk_child[K.nh] = (int8_t)m.joint_child[j]; K.hooke_of_link[m.joint_child[j]] = (int8_t)K.nh; K.nh++;
         }
     }
+    for (int l = 0; l < m.L; l++) if (m.chain_len[l] > KJ_CHAIN) return fail(CPE_BAD_ARG, "skeleton too deep for the kinetic kernels (a marker more than 5 links from the root)");
     K.mu_slack = h->kmus; K.sbox = (opt->slack_hi < 1e9 || opt->slack_lo > -1e9) ? 1 : 0;
     if (K.sbox && (!(opt->kappa_slack > 0) || !(opt->slack_lo < opt->slack_hi))) return fail(CPE_BAD_ARG, "kinetic options: slack box needs lo < hi and a positive penalty");
     if (!h->dk) HIPCHK(hipMalloc(&h->dk, sizeof(DevKin)));
