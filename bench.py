@@ -185,6 +185,12 @@ def cpu_baseline(sk, cams, opts, d, budget_s=8.0):
                                   solves_per_s=nb / tm, solve_sample=f"{nb} sequences on {us} threads, {tm:.1f} s, {float(its.mean()):.1f} iterations on average"))
 
 
+def progress(msg):
+    """one line per finished leg on stderr: a profiler run of this script is silent on stdout until the JSON line, and a watchdog takes minutes of
+    silence for a hang"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def roof_bytes(nbytes, ms):
     """algorithmic bytes over kernel milliseconds against the HBM peak"""
     if not ms:
@@ -475,6 +481,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    progress(f"rank {rank}: inputs generated ({Bgen} sequences)")
     h = _lib.Handle(sk, cams, opts, device=local)
     S = h.S
     t = upload(torch, {k: v[:B] for k, v in d.items()}, dev)
@@ -516,6 +523,7 @@ def main():
     elapsed = max_over_ranks(elapsed)
     frames_total = world * B * N * args.steps
     value = frames_total / elapsed
+    progress(f"rank {rank}: residual + Jacobian pass timed ({kern_ms:.3f} ms per launch)")
     # the variant that also reads the weights and writes the robust cost (k_resjac<true>), for the record
     ms_cost = time_resjac(h, t, r, J, eps, cost, 5, stream) if world == 1 else None
 
@@ -614,13 +622,17 @@ def main():
                 lat[f"N{n1}"] = dict(ms=1e3 * float(np.median(times[1:])), iterations=int(s1[0].iterations), status=int(s1[0].status))
             solves["latency_b1"] = lat
 
+    if solves is not None:
+        progress(f"rank {rank}: solves timed ({solves['value']:.0f} solves/s)")
     cfg3 = cfg4 = None
     if extra:
         h.close()                                          # its 16 GB workspace goes back before the next handles are made
         ts_ = q = dq = ddq = pos = me = None
         torch.cuda.empty_cache()
         cfg3, q3 = bench_cfg3(torch, _lib, abi, skeleton, synth, dev, local, d3, N, cpu=not args.no_cpu)
+        progress(f"config 3 timed ({cfg3['value']:.1f} solves/s)")
         cfg4 = bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, args.cfg4_cams, cpu=not args.no_cpu)
+        progress(f"config 4 timed ({cfg4['value']:.2f} solves/s)")
         h = None
 
     if rank == 0:

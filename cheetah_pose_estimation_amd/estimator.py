@@ -17,7 +17,7 @@ import pickle
 from dataclasses import dataclass, field
 from glob import glob
 from time import time
-from typing import Dict, List, Optional, Tuple
+from typing import Sequence, Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -494,14 +494,11 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
                             total_mass * 9.81, kinematic_model, tables, device, enable_eom_slack=enable_eom_slack, bound_eom_error=bound_eom_error)
 
 
-def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True, monocular_constraints: bool = False,
-                        disable_pose_prior: bool = False, disable_motion_prior: bool = False,
-                        pose_model_num_components: int = 5, motion_model_window_size: int = 4,
-                        motion_model_sparse_solution: bool = True, out_dir_prefix: Optional[str] = None,
-                        q_init: Optional[np.ndarray] = None, options: Optional[abi.Options] = None) -> bool:
-    """Same signature as acinoset_opt.estimate_kinematics (acinoset_opt.py:539-547) plus two optional
-    keyword arguments.  Returns True when the solve converged (IPOPT `ok`+`optimal` in the reference)."""
-    est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
+def _kin_prepare(est: CheetahEstimator, monocular_constraints: bool, disable_pose_prior: bool, disable_motion_prior: bool,
+                 pose_model_num_components: int, motion_model_window_size: int, motion_model_sparse_solution: bool,
+                 q_init: Optional[np.ndarray], options: Optional[abi.Options]):
+    """what estimate_kinematics sets up before the solver call (acinoset_opt.py:565-608): priors, initial guess, options"""
+    params, scene, sk = est.params, est.scene, est.skeleton
     pri = None
     if monocular_constraints and scene.cam_idx is not None and not (disable_pose_prior and disable_motion_prior):
         # acinoset_opt.py:593-600.  The fitted numbers ship as package data (tools/fit_priors.py re-runs the reference's
@@ -522,26 +519,22 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
             q_init[:, 3 + 3 * i + 2] = psi[sl]
     opts = options if options is not None else abi.default_options(scene.fps)
     opts.h = 1.0 / scene.fps
-    h = _lib.Handle(sk, est.cams, opts, pri, device=est.device)
-    try:
-        t0 = time()
-        if params.enable_shutter_delay_estimation and scene.cam_idx is None:
-            # m.shutter_delay, bounds +-hm0, camera 1 fixed (acinoset_misc.py:182-183, 273-275)
-            res = h.solve_shutter_host(q_init[None], est.meas[None], est.weight[None], opts.h, max_rounds=20, tol_tau=1e-5)
-            est.shutter_delay = res["tau"][0]
-        else:
-            res = h.solve_host(q_init[None], est.meas[None], est.weight[None])
-            est.shutter_delay = None
-        est.opt_time_s = time() - t0
-        import torch
-        dev = torch.device("cuda", est.device)
-        qd = torch.tensor(res["q"], device=dev)
-        pos = torch.empty((1, N, 24, 3), dtype=torch.float64, device=dev); com = torch.empty((1, N, 3), dtype=torch.float64, device=dev)
-        h.forward_kinematics(qd, pos, com); h.synchronize()
-        est.com_pos = com[0].cpu().numpy()
-        est.com_vel = (est.com_pos[1:] - est.com_pos[:-1]) * scene.fps     # acinoset_misc.py:742
-    finally:
-        h.close()
+    return q_init, opts, pri
+
+
+def _kin_finish(est: CheetahEstimator, h, res: dict, seconds: float, solver_output: bool, monocular_constraints: bool,
+                out_dir_prefix: Optional[str]) -> bool:
+    """what estimate_kinematics does after the solver call (acinoset_opt.py:619-634): centre of mass, costs, files.  `res` holds ONE sequence."""
+    params, scene = est.params, est.scene
+    N = params.end_frame - params.start_frame
+    est.opt_time_s = seconds
+    import torch
+    dev = torch.device("cuda", est.device)
+    qd = torch.tensor(res["q"], device=dev)
+    pos = torch.empty((1, N, 24, 3), dtype=torch.float64, device=dev); com = torch.empty((1, N, 3), dtype=torch.float64, device=dev)
+    h.forward_kinematics(qd, pos, com); h.synchronize()
+    est.com_pos = com[0].cpu().numpy()
+    est.com_vel = (est.com_pos[1:] - est.com_pos[:-1]) * scene.fps     # acinoset_misc.py:742
     st = res["stats"][0]
     est.result = res
     est.costs = {"measurement": st.cost_meas, "model": st.cost_model, "pose": st.cost_pose, "motion": st.cost_motion}
@@ -557,6 +550,129 @@ def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True,
         fname = fname if scene.cam_idx is None else f"{fname}_{scene.cam_idx}"    # acinoset_opt.py:626-628
         est.save(fname, out_dir_prefix=out_dir_prefix)
     return ok
+
+
+def estimate_kinematics(estimator: CheetahEstimator, solver_output: bool = True, monocular_constraints: bool = False,
+                        disable_pose_prior: bool = False, disable_motion_prior: bool = False,
+                        pose_model_num_components: int = 5, motion_model_window_size: int = 4,
+                        motion_model_sparse_solution: bool = True, out_dir_prefix: Optional[str] = None,
+                        q_init: Optional[np.ndarray] = None, options: Optional[abi.Options] = None) -> bool:
+    """Same signature as acinoset_opt.estimate_kinematics (acinoset_opt.py:539-547) plus two optional
+    keyword arguments.  Returns True when the solve converged (IPOPT `ok`+`optimal` in the reference)."""
+    est, params, scene, sk = estimator, estimator.params, estimator.scene, estimator.skeleton
+    q_init, opts, pri = _kin_prepare(est, monocular_constraints, disable_pose_prior, disable_motion_prior, pose_model_num_components,
+                                     motion_model_window_size, motion_model_sparse_solution, q_init, options)
+    h = _lib.Handle(sk, est.cams, opts, pri, device=est.device)
+    try:
+        t0 = time()
+        if params.enable_shutter_delay_estimation and scene.cam_idx is None:
+            # m.shutter_delay, bounds +-hm0, camera 1 fixed (acinoset_misc.py:182-183, 273-275)
+            res = h.solve_shutter_host(q_init[None], est.meas[None], est.weight[None], opts.h, max_rounds=20, tol_tau=1e-5)
+            est.shutter_delay = res["tau"][0]
+        else:
+            res = h.solve_host(q_init[None], est.meas[None], est.weight[None])
+            est.shutter_delay = None
+        return _kin_finish(est, h, res, time() - t0, solver_output, monocular_constraints, out_dir_prefix)
+    finally:
+        h.close()
+
+
+def _struct_bytes(x) -> bytes:
+    import ctypes as _C
+    return bytes(_C.string_at(_C.addressof(x), _C.sizeof(x)))
+
+
+def estimate_kinematics_batch(estimators: Sequence[CheetahEstimator], solver_output: bool = False, monocular_constraints: bool = False,
+                              disable_pose_prior: bool = False, disable_motion_prior: bool = False, out_dir_prefix: Optional[str] = None,
+                              options: Optional[abi.Options] = None) -> List[bool]:
+    """estimate_kinematics for MANY sequences at once: the loop of run_dataset.py:1145-1196 (`for seq in dataset: init_trajectory; estimate_kinematics`)
+    as batched launches.  Sequences that share a skeleton, a camera rig, a length and a frame rate go through ONE solver handle and ONE cpe_solve
+    call (B = the group's size: the GPU solves thousands of sequences per second batched, one at a time it is latency-bound at 7 - 30 ms each);
+    every sequence then gets its own centre of mass, costs and files exactly as estimate_kinematics writes them.  All estimators must live on the
+    same device; shutter-delay estimation is per sequence (cpe_solve_shutter) and goes through estimate_kinematics.  Returns one bool per
+    estimator, in order."""
+    ests = list(estimators)
+    out: List[Optional[bool]] = [None] * len(ests)
+    groups: Dict[tuple, List[int]] = {}
+    prepared = {}
+    for i, est in enumerate(ests):
+        if est.params.enable_shutter_delay_estimation and est.scene.cam_idx is None:
+            out[i] = estimate_kinematics(est, solver_output, monocular_constraints, disable_pose_prior, disable_motion_prior, out_dir_prefix=out_dir_prefix, options=options)
+            continue
+        q_init, opts, pri = _kin_prepare(est, monocular_constraints, disable_pose_prior, disable_motion_prior, 5, 4, True, None,
+                                         None if options is None else _copy_options(options))
+        prepared[i] = (q_init, opts, pri)
+        key = (_struct_bytes(est.skeleton), b"".join(_struct_bytes(est.cams[c]) for c in range(len(est.cams))), q_init.shape[0], _struct_bytes(opts),
+               None if pri is None else _struct_bytes(pri), est.device)
+        groups.setdefault(key, []).append(i)
+    for idx in groups.values():
+        e0 = ests[idx[0]]
+        _, opts, pri = prepared[idx[0]]
+        h = _lib.Handle(e0.skeleton, e0.cams, opts, pri, device=e0.device)
+        try:
+            t0 = time()
+            res = h.solve_host(np.stack([prepared[i][0] for i in idx]), np.stack([ests[i].meas for i in idx]), np.stack([ests[i].weight for i in idx]))
+            dt = (time() - t0) / len(idx)                                            # processing_time_s of a sequence: its share of the batched solve
+            for b, i in enumerate(idx):
+                one = {k: (v[b:b + 1] if isinstance(v, np.ndarray) else v) for k, v in res.items() if k not in ("stats", "status")}
+                one["stats"] = [res["stats"][b]]; one["status"] = res["stats"][b].status
+                ests[i].shutter_delay = None
+                out[i] = _kin_finish(ests[i], h, one, dt, solver_output, monocular_constraints, out_dir_prefix)
+        finally:
+            h.close()
+    return [bool(v) for v in out]
+
+
+def _copy_options(o: abi.Options) -> abi.Options:
+    import ctypes as _C
+    c = abi.Options()
+    _C.memmove(_C.byref(c), _C.byref(o), _C.sizeof(abi.Options))
+    return c
+
+
+def _dataset_worker(rank: int, n_ranks: int, device: int, jobs: List[dict], estimate_kwargs: dict, queue) -> None:
+    """one process of run_kinematics_dataset: builds the estimators of its shard on its GPU and solves them batched"""
+    from . import sharding
+    try:
+        mine = [int(i) for i in sharding.shard_indices(len(jobs), rank, n_ranks)]
+        ests = [init_trajectory(device=device, **jobs[i]) for i in mine]
+        oks = estimate_kinematics_batch(ests, **estimate_kwargs)
+        queue.put((rank, mine, oks, None))
+    except Exception as exc:                                                          # the parent re-raises
+        import traceback
+        queue.put((rank, [], [], f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"))
+
+
+def run_kinematics_dataset(jobs: Sequence[dict], devices: Sequence[int] = (0,), **estimate_kwargs) -> List[bool]:
+    """A whole data set of sequences across the GPUs of one node (BASELINE config 5; the reference loops over them one by one on the CPU,
+    run_dataset.py:1143-1231).  jobs: one dictionary of init_trajectory keyword arguments per sequence (root_dir, data_path, cheetah_name,
+    kinetic_dataset, kinematic_model=True, ...).  Sequence i goes to rank i mod G (sharding.shard_indices: independent sequences, no collective on
+    the solve path); every rank is a FRESH process started before it touches its GPU (spawn, not fork), builds its estimators with init_trajectory
+    (DLC tables -> measurement tensors on its GPU), solves them with estimate_kinematics_batch and writes each sequence's files.  Returns one bool
+    per job, in order.  devices may name one GPU several times (rehearsal of the multi-rank path on a one-GPU box)."""
+    jobs = [dict(j) for j in jobs]
+    G = len(devices)
+    if G == 1:
+        ests = [init_trajectory(device=devices[0], **j) for j in jobs]
+        return estimate_kinematics_batch(ests, **estimate_kwargs)
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_dataset_worker, args=(r, G, int(devices[r]), jobs, estimate_kwargs, queue)) for r in range(G)]
+    for p_ in procs:
+        p_.start()
+    results, errors = [None] * len(jobs), []
+    for _ in range(G):
+        rank, mine, oks, err = queue.get()
+        if err:
+            errors.append(f"rank {rank}: {err}")
+        for i, ok in zip(mine, oks):
+            results[i] = bool(ok)
+    for p_ in procs:
+        p_.join()
+    if errors:
+        raise RuntimeError("run_kinematics_dataset: " + " | ".join(errors))
+    return results
 
 
 def determine_contacts(estimator: CheetahEstimator, monocular: bool = False, verbose: bool = True,

@@ -59,3 +59,33 @@ def test_sharded_sequences_over_two_ranks_equal_one_process():
         assert full[i][1] == st == 0 and full[i][2] == it
         assert full[i][0] == qb                                    # bit for bit
         assert np.isfinite(np.frombuffer(qb)).all()
+
+
+def test_dataset_entry_batches_and_shards_sequences(tmp_path):
+    """run_kinematics_dataset -- the loop of run_dataset.py:1143-1196 as a product function.  Five synthetic sequences on disk
+    (two lengths: two solver groups), (a) one at a time through estimate_kinematics, (b) batched in this process (estimate_kinematics_batch groups
+    them by skeleton / rig / length into cpe_solve calls with B > 1), (c) dealt to two fresh processes, one rank each (both on cuda:0 on this
+    one-GPU box), by sharding.shard_indices.  Every sequence's fte.pickle is the same in all three, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from cheetah_pose_estimation_amd import estimator as E
+    from dataset_util import write_dataset
+    roots = {k: str(tmp_path / k) for k in ("single", "batch", "multi")}
+    specs = [("2019_03_07/synth/run1", 24, 5), ("2019_03_07/synth/run2", 24, 6), ("2019_03_07/synth/run3", 30, 7), ("2019_03_07/synth/run4", 24, 8), ("2019_03_07/synth/run5", 30, 9)]
+    for root in roots.values():
+        for path, N, seed in specs:
+            write_dataset(root, data_path=path, N=N, seed=seed)
+    jobs = lambda root: [dict(root_dir=root, data_path=path, cheetah_name="phantom", kinetic_dataset=False, solver_path="/unused/ipopt", kinematic_model=True)
+                         for path, _, _ in specs]
+    oks_single = [E.estimate_kinematics(E.init_trajectory(**j), solver_output=False) for j in jobs(roots["single"])]
+    oks_batch = E.run_kinematics_dataset(jobs(roots["batch"]), devices=(0,))
+    oks_multi = E.run_kinematics_dataset(jobs(roots["multi"]), devices=(0, 0))
+    assert oks_single == oks_batch == oks_multi == [True] * 5
+    for path, N, _ in specs:
+        ref = E.load_result_pickle(os.path.join(roots["single"], path, "fte_kinematic", "fte.pickle"))
+        assert ref["q"].shape == (N, 54)
+        for k in ("batch", "multi"):
+            got = E.load_result_pickle(os.path.join(roots[k], path, "fte_kinematic", "fte.pickle"))
+            for key in ("q", "dq", "ddq", "positions", "x", "com_pos", "meas_err"):
+                assert np.array_equal(ref[key], got[key]), (k, path, key)
+            assert got["obj_cost"] == ref["obj_cost"] and os.path.exists(os.path.join(roots[k], path, "fte_kinematic", "cam6_fte.csv"))
