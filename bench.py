@@ -312,13 +312,13 @@ def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu
     el = time.perf_counter() - t0
     its = np.array([s_.iterations for s_ in stats]); stt = np.array([s_.status for s_ in stats])
     wni = float((np.array([s_.iterations for s_ in wstats]) + 1).sum()) * (N - 2)    # node-iterations of the profiled run
-    nrow, nlat, nc3, nq = sk.nq + 3 * nf + 3 * 24, nm + nc + 3 * nf, 84, sk.nq
+    nrow, nlat, nc3, nq = sk.nq + 4 * nf + 3 * 24, nm + nc + 3 * nf, 84, sk.nq
     KP = nc3 * nc3 + 64 * nc3 + 64 * 64
     byts = dict(k_dyn_eval=8 * (3 * 66 + 64 + 76 + 2 * nq + 2 * nrow + nq * 64 + 64 * 64 + 64 + 8 + nq),      # states, warm start, multipliers in; row gradient / weight, A, H_ff, forces, record, slack out
                 k_dyn_jac=8 * (3 * 66 + 64 + nrow * nc3),                                                       # states, forces in; J out
                 k_dyn_assemble=8 * (nrow * nc3 + 2 * nrow + nq * 64 + nc3 * nc3 + 64 * nc3 + nc3),                 # J, A in; H_uu, H_fu, gradient out
                 k_dyn_schur=8 * (KP + 64 + 68 + 6 * 28 * 28),                                                       # the three pieces in; six blocks out
-                k_dyn_gather=8 * (3 * 6 * 28 * 28 + 28 * 28 + 3 * nc3 + 28 + 28 * 28 + 3 * 28 * 28 + 28))           # three nodes' blocks in; band blocks + gradient out
+                k_dyn_gather=8 * (11 * 28 * 28 + 5 * 28))            # measurement block + the six blocks of three nodes that touch the frame in; B, three band blocks, gradient out
     fl = kinetic_flops_per_node(nq, nrow, nlat, nc3, nm + nc)
     ms = {k: v[0] for k, v in prof.items()}; nl = {k: v[1] for k, v in prof.items()}
     kern = {}
@@ -414,6 +414,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 (monocular + learned priors) and config-4 (physics-based) solve timings")
     ap.add_argument("--cfg3-batch", type=int, default=256)
     ap.add_argument("--cfg4-batch", type=int, default=64)
+    ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the synthetic sequences (0 = as many as the CPU share allows; 1 under a profiler, whose preloaded tool does not survive fork)")
     ap.add_argument("--cfg4-cams", type=int, default=6, choices=(1, 6), help="cameras of the physics-based timing (1 = monocular + pose prior, as the reference runs it)")
     args = ap.parse_args()
 
@@ -458,7 +459,7 @@ def main():
     # global index b has seed 1234 + b; the global list is dealt to the ranks round-robin: no two ranks (and no two slots of a rank) share one
     B = args.batch
     Bgen = max(B, 0 if args.no_solve else args.solve_batch)
-    workers = max(1, min(16, usable_cores()[0] // max(1, min(world, 8))))
+    workers = args.gen_workers if args.gen_workers > 0 else max(1, min(16, usable_cores()[0] // max(1, min(world, 8))))
     mine = sharding.shard_indices(world * Bgen, rank, world)
     d = make_sequences("run", L, None, N, [1234 + int(i) for i in mine], workers)
     d24 = make_sequences("run", 24, None, N, [1234 + int(i) for i in mine[:B]], workers) if (L == 25 and world == 1 and not args.no_l24) else None

@@ -1078,7 +1078,7 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
     for (int j = 0; j < m.nj; j++)
         for (int t = (m.joint_kind[j] == CPE_JOINT_REVOLUTE_Y ? 0 : 1); t < 2; t++) { K.con_joint[K.nc] = j; K.con_axis[K.nc] = t == 0 ? 0 : 2; K.nc++; }
     K.nlat = K.nm + K.nc + 3 * K.nf;
-    if (K.nlat > KIN_LS || K.nm + K.nc > 52) return fail(CPE_BAD_ARG, "more than 64 node forces");
+    if (K.nlat > KIN_NA_MAX || K.nm + K.nc > 52) return fail(CPE_BAD_ARG, "more than 60 node forces");
     K.nrow = m.nq + 4 * K.nf + 3 * m.L;          // slack | foot heights | foot velocities (x, y, z) | second differences of the markers
     // the evaluation slots of k_dyn_eval are laid out for the reference's skeleton (KS_* in cpe_kinetic.hip.inc): anything larger is refused here,
     // not truncated there
@@ -1134,10 +1134,8 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
     return CPE_OK;
 }
 
-static size_t lds_kin_eval() {
-    const size_t x = std::max<size_t>(8 * (size_t)KIN_SLOT, 2 * (size_t)KIN_LS * KIN_LS + 2048);
-    return sizeof(double) * ((sizeof(KinShared) + 7) / 8 + (size_t)CPE_MAX_NQ * KIN_LS + x);
-}
+static_assert(KE_R1 >= KS_NQ * KIN_LS && KE_R1 >= KIN_SLOT && KE_R2 >= 3 * KIN_SLOT, "regions of k_dyn_eval hold A, an evaluation slot / the three base slots");
+static size_t lds_kin_eval() { return sizeof(double) * ((sizeof(KinShared) + 7) / 8 + (size_t)KE_R1 + KE_R2); }
 static size_t lds_kin_assemble() { return sizeof(double) * ((size_t)KIN_ROWS_MAX * KIN_NC3 + (size_t)CPE_MAX_NQ * KIN_LS + 2 * KIN_ROWS_MAX); }
 static size_t lds_kin_schur() { return sizeof(double) * ((size_t)KIN_LS * KIN_LS + (size_t)KIN_LS * KIN_NC3); }
 

@@ -864,6 +864,7 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
 
 /* Levenberg-Marquardt over the whole trajectory in reduced coordinates (stands where IPOPT is called,
  * acinoset_opt.py:611-617).  Same algorithm as the HIP product (DESIGN.md "Solver"). */
+#define CPO_DIAG_FLOOR(N) ((N) < 4 ? 0.1 : 1e-12)
 typedef struct { const double* tau; double* rcb; double* mu_keep; } shutter_t;
 static cpe_status solve_impl2(const cpe_skeleton* s, const cpe_camera* cams, int C, const cpe_options* o,
                               const cpe_priors* pr, int N, const double* q_init, const double* meas,
@@ -910,7 +911,12 @@ static cpe_status solve_impl2(const cpe_skeleton* s, const cpe_camera* cams, int
             kin_add_schur(&x, N, kd, lam, abf);
             memcpy(abm, abf, sizeof(double) * (size_t)n_tot * (kd + 1));        /* the model matrix of this iteration (for pred) */
         }
-        for (int i = 0; i < n_tot; i++) { double d = abf[(size_t)i * (kd + 1)]; abf[(size_t)i * (kd + 1)] = d + lam * (d > 1e-12 ? d : 1e-12); }
+        /* Marquardt scaling lam * diag(H) with a FLOOR on the diagonal for sequences without a motion term (N < 4: no third difference exists): a
+         * coordinate that no measurement of its frame sees (weights zero, outliers in the flat part of the loss) is tied to nothing there, its diagonal
+         * is ~0 and scaling alone leaves it undamped -- steps of 30 rad in such coordinates made sequences of 2 and 3 frames creep to the iteration
+         * limit (round 2's three expected failures).  From 4 frames on the floor is the old guard against an exact zero (a larger one slows the
+         * weakly observed directions next to the Euler pole: 200 instead of 38 iterations).  Same rule in csrc/cpe_solver.hip.inc */
+        for (int i = 0; i < n_tot; i++) { double d = abf[(size_t)i * (kd + 1)]; abf[(size_t)i * (kd + 1)] = d + lam * fmax(d, CPO_DIAG_FLOOR(N)); }
         if (band_cholesky(n_tot, kd, abf)) { lam *= 10; if (lam > 1e12) { status = CPE_NUMERICAL; } continue; }
         for (int i = 0; i < n_tot; i++) dl[i] = -g[i];
         band_solve(n_tot, kd, abf, dl);

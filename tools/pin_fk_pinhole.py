@@ -170,7 +170,7 @@ def main():
     for r, (c, j) in enumerate(rows):
         spars[2 * r:2 * r + 2, c * 15:(c + 1) * 15] = 1; spars[2 * r:2 * r + 2, C * 15 + 3 * j:C * 15 + 3 * j + 3] = 1
     sol = least_squares(lambda p: res_ba(*unpack(p)), np.concatenate([cams.ravel(), X[idx].ravel()]), jac_sparsity=spars, method="trf", x_scale="jac",
-                        ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300)
+                        ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=150)
     cams, Xi = unpack(sol.x)
     print(f"after point BA: rms {np.sqrt(np.mean(sol.fun**2)):.3e} px, nfev {sol.nfev}")
     X[idx] = Xi
@@ -220,6 +220,29 @@ def main():
     print(f"skeleton fit to the 3D points: rms {np.sqrt(np.mean(s3.fun**2)) * 1e3:.4f} mm, nfev {s3.nfev}")
     nU = N * len(ind)
     okc = ok.transpose(1, 0, 2)                                  # [C, N, L]
+    # From here on every leg link is its body rotated about the body's y axis by alpha (the solver's own coordinates): both solution
+    # branches of the joint equalities are covered smoothly -- limbs of these gallops swing beyond the horizontal
+    lay = synth.leg_layout(sk)
+    leg_pos = [list(ind).index(3 + 3 * c + 1) for c, _ in lay]
+
+    def q_from_ua(u):
+        U = u.reshape(N, len(ind))
+        q = np.zeros((N, sk.nq)); q[:, ind] = U
+        for c, _ in lay:
+            q[:, 3 + 3 * c + 1] = 0.0
+        for i in range(1, sk.n_links):
+            if (3 + 3 * i + 2) not in ind:
+                q[:, 3 + 3 * i + 2] = q[:, 5]
+        q = synth.legs_from_alpha(sk, q, U[:, leg_pos])
+        return synth.project_dependents_numpy_hooke(sk, q)
+    qs = q_from_u(s3.x)
+    ua = qs[:, ind].copy()
+    for r, (c, B) in enumerate(lay):
+        RB = synth.rot_zyx(qs[:, 3 + 3 * B:6 + 3 * B]); Rc = synth.rot_zyx(qs[:, 3 + 3 * c:6 + 3 * c])
+        Mx = np.einsum("nji,njk->nik", RB, Rc)
+        ua[:, leg_pos[r]] = np.arctan2(Mx[:, 0, 2], Mx[:, 0, 0])
+    s3 = type("S", (), {"x": ua.ravel()})
+    q_from_u = q_from_ua
 
     def fun_joint(p):
         pos = synth.fk_numpy(sk, q_from_u(p[:nU]))[0]
@@ -231,8 +254,8 @@ def main():
             r0 = (c * N + n) * L * 2
             spj[r0:r0 + L * 2, n * len(ind):(n + 1) * len(ind)] = 1; spj[r0:r0 + L * 2, nU + c * 15:nU + (c + 1) * 15] = 1
     pj = np.concatenate([s3.x, cams.ravel()])
-    for rnd in range(4):
-        sj = least_squares(fun_joint, pj, jac_sparsity=spj, method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=500)
+    for rnd in range(6):
+        sj = least_squares(fun_joint, pj, jac_sparsity=spj, method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=400)
         pj = sj.x
         print(f"joint refinement round {rnd}: rms {np.sqrt((sj.fun**2).sum() / (2 * ok.sum())):.3e} px, max {np.abs(sj.fun).max():.3e} px, nfev {sj.nfev}")
         if np.abs(sj.fun).max() < 1e-6:
