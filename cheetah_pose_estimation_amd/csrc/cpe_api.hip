@@ -1136,8 +1136,8 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
 
 static_assert(KE_R1 >= KS_NQ * KIN_LS && KE_R1 >= KIN_SLOT && KE_R2 >= 3 * KIN_SLOT, "regions of k_dyn_eval hold A, an evaluation slot / the three base slots");
 static size_t lds_kin_eval() { return sizeof(double) * ((sizeof(KinShared) + 7) / 8 + (size_t)KE_R1 + KE_R2); }
-static size_t lds_kin_assemble() { return sizeof(double) * ((size_t)KIN_ROWS_MAX * KIN_NC3 + (size_t)CPE_MAX_NQ * KIN_LS + 2 * KIN_ROWS_MAX); }
-static size_t lds_kin_schur() { return sizeof(double) * ((size_t)KIN_LS * KIN_LS + (size_t)KIN_LS * KIN_NC3); }
+static size_t lds_kin_assemble() { return sizeof(double) * ((size_t)KA_RC * KA_RS + (size_t)KS_NQ * KIN_LS + 2 * KS_NROW); }
+static size_t lds_kin_schur() { return sizeof(double) * ((size_t)(KIN_NA_MAX + KIN_NC3) * KIN_MS + KIN_LS); }
 
 static cpe_status ensure_kws(cpe_handle* h, int B, int N) {
     const size_t F = (size_t)B * N;

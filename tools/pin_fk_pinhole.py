@@ -119,6 +119,9 @@ def main():
     okf = lambda c: ok[:, c].reshape(-1)
     pairs = sorted(((int((okf(a) & okf(b)).sum()), a, b) for a in range(C) for b in range(a + 1, C)), reverse=True)
     _, ca, cb = pairs[0]
+    if os.environ.get("PIN_PAIR"):                               # another starting pair (the one with most common points can be close to degenerate)
+        ca, cb = (int(v) - 1 for v in os.environ["PIN_PAIR"].split(","))
+    print("pairs by common points:", [(a + 1, b + 1, n) for n, a, b in pairs])
     both = okf(ca) & okf(cb)
     best = None
     for f in np.geomspace(500, 6000, 60):
