@@ -1107,6 +1107,23 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
                 K.blk[i][k] = (int16_t)K.nblk; K.blk_i[K.nblk] = (int8_t)i; K.blk_k[K.nblk] = (int8_t)k; K.nblk++;
             }
         }
+        for (int bl = 0; bl < K.nblk; bl++) {
+            const int i = K.blk_i[bl], k = K.blk_k[bl];
+            int nmo = 0, nco = 0;
+            for (int mo = 0; mo < K.nm; mo++) {
+                const int a1 = d.motor_first[mo], a2 = d.motor_second[mo];
+                if (a1 == a2 || (i != a1 && i != a2) || (k != i && k != a1)) continue;
+                if (nmo >= KJ_LMAX) return fail(CPE_BAD_ARG, "more motors on one link pair than the kinetic kernels are sized for");
+                K.bm[bl][nmo++] = (uint8_t)mo;
+            }
+            for (int r = 0; r < K.nc; r++) {
+                const int p = m.joint_parent[K.con_joint[r]], ch = m.joint_child[K.con_joint[r]];
+                if (!((i == p || i == ch) && (k == p || k == ch))) continue;
+                if (nco >= KJ_LMAX) return fail(CPE_BAD_ARG, "more joint equalities on one link pair than the kinetic kernels are sized for");
+                K.bc[bl][nco++] = (uint8_t)r;
+            }
+            K.bm_n[bl] = (uint8_t)nmo; K.bc_n[bl] = (uint8_t)nco;
+        }
         std::vector<double> msub(nl, 0.0);
         for (int i = 0; i < nl; i++) for (int j = 0; j < nl; j++) if (j == i || is_anc(i, j)) msub[i] += m.mass[j];
         K.mtot = mt;
