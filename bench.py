@@ -413,7 +413,7 @@ def main():
     ap.add_argument("--no-l24", action="store_true", help="skip the extra 24-marker residual+Jacobian measurement")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 (monocular + learned priors) and config-4 (physics-based) solve timings")
     ap.add_argument("--cfg3-batch", type=int, default=256)
-    ap.add_argument("--cfg4-batch", type=int, default=64)
+    ap.add_argument("--cfg4-batch", type=int, default=128)
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the synthetic sequences (0 = as many as the CPU share allows; 1 under a profiler, whose preloaded tool does not survive fork)")
     ap.add_argument("--cfg4-cams", type=int, default=6, choices=(1, 6), help="cameras of the physics-based timing (1 = monocular + pose prior, as the reference runs it)")
     args = ap.parse_args()

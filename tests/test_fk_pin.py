@@ -211,3 +211,53 @@ def test_oracle_solver_on_the_real_run(oracle):
     assert st.max_bound_violation < 1e-5 and st.max_constraint < 1e-12
     err = np.sqrt(((res["positions"] - oracle.markers(sk, q_ref)) ** 2).sum(-1))
     assert np.sqrt((err ** 2).mean()) < 0.008 and err.max() < 0.04
+
+
+def _cams_pinhole(Zp):
+    """cameras of a kinetic-dataset fixture (tools/pin_fk_pinhole.py): [fx fy cx cy | k1 k2 p1 p2 k3 | rvec | t] in OpenCV's order.  The reference's
+    pinhole model (acinoset_misc.py:1682-1696) is purely radial, 1 + D0 r^2 + D1 r^4 + D2 r^6; the fit left the tangential pair free and found
+    |p1|, |p2| < 4e-7, which is how the stored files say that the model has no such terms.  They are dropped here (< 1e-4 px)."""
+    C = Zp["cams"].shape[0]
+    cams = (abi.Camera * C)()
+    for c in range(C):
+        p = Zp["cams"][c]
+        cam = cams[c]
+        cam.model = abi.CAM_PINHOLE
+        cam.fx, cam.fy, cam.cx, cam.cy = p[0:4]
+        cam.D[0], cam.D[1], cam.D[2], cam.D[3] = p[4], p[5], p[8], 0.0
+        R = _rodrigues(p[9:12]) if np.linalg.norm(p[9:12]) > 0 else np.eye(3)
+        for i in range(9):
+            cam.R[i] = R.reshape(-1)[i]
+        for i in range(3):
+            cam.t[i] = p[12 + i]
+        cam.mult = 1.0
+    return cams
+
+
+KINETIC_PINS = [f for f in ("fk_csv_pin_arabia.npz", "fk_csv_pin_shiraz.npz") if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", f))]
+
+
+@pytest.mark.parametrize("fixture", KINETIC_PINS)
+def test_kinetic_dataset_pinhole_rig(oracle, fixture):
+    """the only reference-held fixtures for the `-02` skeletons and the four-camera pinhole rig of the kinetic dataset --
+    data/test_set/kinetic_dataset/<day>/<animal>/<trial>/fte_kinematic/cam{1..4}_fte.csv (the reference's reprojection of its own FK at its solution,
+    empty cells where a marker leaves the 1280 x 720 image).  tools/pin_fk_pinhole.py recovered joint angles and camera parameters from those
+    numbers alone (focal scan + two-view geometry -> bundle adjustment -> skeleton fit -> joint refinement in the solver's own leg-angle
+    coordinates).  The `<animal>-02` link table, the FK chain, the marker offsets, the 26 joint equalities and the pinhole + radial projection
+    reproduce every stored number to < 1e-4 px (arabia: 4 335 visible points, max 8.1e-5 px, rms 2.1e-5 px; the fit itself, with its two free
+    tangential terms, closes to 6.7e-6 px)."""
+    Zp = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    animal = str(Zp["animal"])
+    sk = skeleton.build_skeleton(f"{animal}-02", 24, kinetic_dataset=True)
+    q, uv = Zp["q"], Zp["uv"]
+    assert uv.shape[1:] == (4, 24, 2) and q.shape == (uv.shape[0], 54)
+    cams = _cams_pinhole(Zp)
+    pos = oracle.markers(sk, q)
+    got = np.array([[[oracle.project(cams[c], pos[n, l]) for l in range(24)] for c in range(4)] for n in range(q.shape[0])])
+    seen = ~np.isnan(uv).any(-1)
+    assert seen.sum() > 3000 and 0.02 < (~seen).mean() < 0.3          # the gaps are part of the fixture
+    err = np.abs(got - uv)[seen]
+    assert err.max() < 1e-4, err.max()
+    assert np.sqrt((err ** 2).mean()) < 3e-5
+    assert max(np.abs(oracle.constraints(sk, x)).max() for x in q) < 1e-12
+    assert np.abs(Zp["cams"][:, 6:8]).max() < 1e-6                     # no tangential distortion in the stored numbers

@@ -312,6 +312,17 @@ def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_
         missing = np.isnan(Zs["uv"]).any(-1)
         rs = hs.eval_resjac_host(Zs["q"][None], np.ascontiguousarray(np.nan_to_num(Zs["uv"])[None]), np.ones((1, n, 6, 24)))[0][0]
         assert np.abs(rs[~missing]).max() < tol, (fx, np.abs(rs[~missing]).max())
+    # the kinetic dataset: four pinhole + radial cameras, `-02` skeletons, NaN gaps (tests/test_fk_pin.py::test_kinetic_dataset_pinhole_rig)
+    from test_fk_pin import KINETIC_PINS, _cams_pinhole
+    assert KINETIC_PINS
+    for fx in KINETIC_PINS:
+        Zs = np.load(os.path.join(os.path.dirname(__file__), "golden", fx))
+        sks = skeleton.build_skeleton(f"{str(Zs['animal'])}-02", 24, kinetic_dataset=True)
+        hs = gpu_handle_factory(sks, _cams_pinhole(Zs))
+        n = Zs["q"].shape[0]
+        missing = np.isnan(Zs["uv"]).any(-1)
+        rs = hs.eval_resjac_host(Zs["q"][None], np.ascontiguousarray(np.nan_to_num(Zs["uv"])[None]), np.ones((1, n, 4, 24)))[0][0]
+        assert np.abs(rs[~missing]).max() < 1e-4, (fx, np.abs(rs[~missing]).max())
 
 
 def test_solve_on_the_real_run_matches_oracle(oracle, gpu_handle_factory):
@@ -477,11 +488,13 @@ def test_solve_with_learned_priors_matches_oracle(which, cams6, oracle, gpu_hand
 
 
 def test_monocular_solve_with_learned_priors(cams6, oracle, gpu_handle_factory):
-    """config 3 as the reference runs it: ONE camera + both priors.  Depth is then weakly observable and the landscape is
-    flat enough that two implementations of one algorithm part ways after ~50 iterations of round-off (measured: HIP and
-    oracle end up to decimetres apart with costs within a few percent, either one lower), so the parity statement here
-    is on the objective: every term the HIP solver reports is the oracle's value at the HIP solution, the joint
-    equalities hold, and the cost went down from the start."""
+    """config 3 as the reference runs it: ONE camera + both priors, 40 frames.  Depth is then weakly observable and the landscape is flat enough
+    that two implementations of one algorithm part ways after ~50 iterations of round-off (measured in round 2: HIP and oracle end up to decimetres
+    apart with costs within a few percent, either one lower), so the statement is minimiser parity, not path parity: the HIP solve CONVERGES
+    (status OK, no iteration limit accepted), every term it reports is the oracle's value at its solution, and the oracle RESTARTED at the HIP
+    solution (damping back at lambda0) stays in the same valley: it converges too, lowers the cost by less than 1e-3 of its value and moves the
+    markers by millimetres (measured: sequence 0 -- 49 more iterations, cost 3.205139 -> 3.203846, 1.3 mm; the stop rule is a relative decrease
+    per iteration, which a flat valley satisfies before its floor is reached; the oracle restarted at its OWN end point moves 1.5e-6 m)."""
     from cheetah_pose_estimation_amd import priors
     sk = skeleton.build_skeleton("phantom", 24)
     pr = priors.load_priors()
@@ -492,7 +505,7 @@ def test_monocular_solve_with_learned_priors(cams6, oracle, gpu_handle_factory):
     out = h.solve_host(d["q_init"], d["meas"], d["weight"])
     for b in range(2):
         st = out["stats"][b]
-        assert st.status in (abi.OK, abi.MAX_ITER)
+        assert st.status == abi.OK, (b, st.status, st.iterations)
         f, _, _, terms, _ = oracle.objective(sk, cam1, opts, pr, out["q"][b], d["meas"][b], d["weight"][b])
         assert abs(st.cost - opts.cost_scale * f) < 1e-9 * abs(st.cost)
         assert abs(st.cost_meas - terms[0]) < 1e-8 * abs(terms[0]) and abs(st.cost_model - terms[1]) < 1e-6 * max(1.0, abs(terms[1]))
@@ -500,6 +513,12 @@ def test_monocular_solve_with_learned_priors(cams6, oracle, gpu_handle_factory):
         f0 = oracle.objective(sk, cam1, opts, pr, d["q_init"][b], d["meas"][b], d["weight"][b])[0]
         assert f < 0.5 * f0
         assert max(np.abs(oracle.constraints(sk, x)).max() for x in out["q"][b]) < 1e-12
+        again = oracle.solve(sk, cam1, opts, pr, out["q"][b], d["meas"][b], d["weight"][b])
+        moved = float(np.sqrt(((again["positions"] - out["positions"][b]) ** 2).sum(-1).mean()))
+        print(f"monocular N=40 sequence {b}: HIP {st.iterations} iterations, cost {st.cost:.9f}; oracle restarted there: {again['stats'].iterations} iterations, "
+              f"cost {again['stats'].cost:.9f}, markers move {moved:.2e} m")
+        assert again["stats"].status == abi.OK
+        assert moved < 5e-3 and 0.0 <= st.cost - again["stats"].cost + 1e-9 and st.cost - again["stats"].cost < 1e-3 * abs(st.cost)
 
 
 def test_monocular_config3_200_frames(cams6, oracle, gpu_handle_factory):
