@@ -314,7 +314,7 @@ def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu
     wni = float((np.array([s_.iterations for s_ in wstats]) + 1).sum()) * (N - 2)    # node-iterations of the profiled run
     nrow, nlat, nc3, nq = sk.nq + 4 * nf + 3 * 24, nm + nc + 3 * nf, 84, sk.nq
     KP = nc3 * nc3 + 64 * nc3 + 64 * 64
-    byts = dict(k_dyn_eval=8 * (3 * 66 + 64 + 76 + 2 * nq + 2 * nrow + nq * 64 + 64 * 64 + 64 + 8 + nq),      # states, warm start, multipliers in; row gradient / weight, A, H_ff, forces, record, slack out
+    byts = dict(k_dyn_eval=8 * (3 * 66 + 64 + 76 + 2 * nq + 2 * nrow + nq * 64 + nq * nlat + 64 * 64 + 64 + 8 + nq),      # states, warm start, multipliers in; row gradient / weight, A (out, and read back once for e = r0 - A f), H_ff, forces, record, slack out
                 k_dyn_jac=8 * (3 * 66 + 64 + nrow * nc3),                                                       # states, forces in; J out
                 k_dyn_assemble=8 * (nrow * nc3 + 2 * nrow + nq * 64 + nc3 * nc3 + 64 * nc3 + nc3),                 # J, A in; H_uu, H_fu, gradient out
                 k_dyn_schur=8 * (KP + 64 + 68 + 6 * 28 * 28),                                                       # the three pieces in; six blocks out
@@ -582,7 +582,7 @@ def main():
         roof = {"bound": "hbm", "kernel": "k_lm_step<3> + k_lm_back<3>", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
                 "achieved": (lm_b * wframe_its / (lm_ms * 1e-3) / 1e9) if lm_ms else None,
                 "frac": (lm_b * wframe_its / (lm_ms * 1e-3) / HBM_PEAK) if lm_ms else None,
-                "traffic": pmc_traffic(min(Bs, 512), N, C, L, "k_lm_step"),          # per full launch window (512 sequences)
+                "traffic": (lambda a_, b_: a_ + b_ if a_ is not None and b_ is not None else a_)(pmc_traffic(min(Bs, 512), N, C, L, "k_lm_step"), pmc_traffic(min(Bs, 512), N, C, L, "k_lm_back")),   # both kernels, per full launch window (512 sequences)
                 "bytes_per_frame_iteration": lm_b, "kernel_ms_total": lm_ms, "launches": lm_n,
                 "ms_per_launch": {"k_lm_step": fwd_ms / lm_n if lm_n else None, "k_lm_back": bk_ms / lm_n if lm_n else None,
                                   "k_frame_normal": fn_ms / fn_n if fn_n else None},

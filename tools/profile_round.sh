@@ -13,8 +13,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/${R}_stats -o ${R} -- python3 /root/rep
 python3 $T/export_rocprof_stats.py /tmp/${R}_stats/${R}_results.db $OUT/${R}_kernel_stats.csv && echo "stats pass done" &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/${R}_pmc_fetch -o ${R} -- python3 /root/repo/bench.py $PMC_ARGS > $OUT/${R}_pmc_fetch.log 2>&1 && echo "fetch pass done" &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/${R}_pmc_write -o ${R} -- python3 /root/repo/bench.py $PMC_ARGS > $OUT/${R}_pmc_write.log 2>&1 && echo "write pass done" &&
-python3 $T/summarise_pmc.py /tmp/${R}_pmc_fetch /tmp/${R}_pmc_write $OUT/${R}_pmc.json 102400 "k_resjac<false=32160" "k_lm_step<4, 0>=60272" "k_frame_normal<false>=11504" &&
-PMC_C=1 python3 $T/summarise_pmc.py /tmp/${R}_pmc_fetch /tmp/${R}_pmc_write $OUT/${R}_pmc_cfg4.json 3168 "k_dyn_eval=67264" "k_dyn_jac=97520" "k_dyn_assemble=225472" "k_dyn_schur=170912" "k_dyn_gather=70112" &&
+python3 $T/summarise_pmc.py /tmp/${R}_pmc_fetch /tmp/${R}_pmc_write $OUT/${R}_pmc.json 102400 "k_resjac<false=32160" "k_lm_step<3, 0>=33776" "k_lm_back<3>=26496" "k_frame_normal<true>=11504" &&
+PMC_C=1 python3 $T/summarise_pmc.py /tmp/${R}_pmc_fetch /tmp/${R}_pmc_write $OUT/${R}_pmc_cfg4.json 3168 "k_dyn_eval=93184" "k_dyn_jac=97520" "k_dyn_assemble=225472" "k_dyn_schur=170912" "k_dyn_gather=70112" &&
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d /tmp/${R}_pmc_sq -o ${R} -- python3 /root/repo/bench.py $PMC_ARGS > $OUT/${R}_pmc_sq.log 2>&1 &&
 python3 $T/export_rocprof_stats.py /tmp/${R}_pmc_sq/${R}_results.db $OUT/${R}_pmc_sq.csv counters && echo "sq pass done"
 rc=$?
