@@ -501,13 +501,18 @@ def _kin_prepare(est: CheetahEstimator, monocular_constraints: bool, disable_pos
     params, scene, sk = est.params, est.scene, est.skeleton
     pri = None
     if monocular_constraints and scene.cam_idx is not None and not (disable_pose_prior and disable_motion_prior):
-        # acinoset_opt.py:593-600.  The fitted numbers ship as package data (tools/fit_priors.py re-runs the reference's
-        # recipe: 5-component GMM, window-4 multi-task lasso); other sizes would need a refit.
-        if (not disable_pose_prior and pose_model_num_components != 5) or \
-                (not disable_motion_prior and (motion_model_window_size != 4 or not motion_model_sparse_solution)):
-            raise NotImplementedError("only the reference's defaults (5 GMM components, sparse window-4 motion model) are packaged")
+        # acinoset_opt.py:593-600.  The fitted numbers of the defaults ship as package data (tools/fit_priors.py re-runs the reference's recipe:
+        # 5-component GMM, window-4 multi-task lasso); another size -- the grid search of run_dataset.py:814-915 -- is fitted here as the reference
+        # does at run time (priors.fit_priors: up to 8 components, windows up to 4 frames) and cached.
         from . import priors as _priors
-        pri = _priors.load_priors(pose=not disable_pose_prior, motion=not disable_motion_prior)
+        default = (disable_pose_prior or pose_model_num_components == 5) and \
+            (disable_motion_prior or (motion_model_window_size == 4 and motion_model_sparse_solution))
+        if default:
+            pri = _priors.load_priors(pose=not disable_pose_prior, motion=not disable_motion_prior)
+        else:
+            path = _priors.fit_priors(5 if disable_pose_prior else pose_model_num_components, 4 if disable_motion_prior else motion_model_window_size,
+                                      True if disable_motion_prior else motion_model_sparse_solution)
+            pri = _priors.load_priors(pose=not disable_pose_prior, motion=not disable_motion_prior, path=path)
     N = params.end_frame - params.start_frame
     if q_init is None:
         base_len = 2.0 * abs(sk.marker_off[5][0])

@@ -461,13 +461,20 @@ def test_pose_prior_frame_term_matches_oracle(cams6, oracle, gpu_handle_factory)
             assert np.abs(Bm[b, n] - Bo).max() < 2e-6 * np.abs(Bo).max()
 
 
-@pytest.mark.parametrize("which", ["pose", "motion", "both"])
+@pytest.mark.parametrize("which", ["pose", "motion", "both", "both-k3-w2-dense"])
 def test_solve_with_learned_priors_matches_oracle(which, cams6, oracle, gpu_handle_factory):
     """GMM pose prior and window-4 autoregressive motion prior in the solver (block-pentadiagonal normal equations for
-    the latter, k_lm_step<4>), on two cameras so that the problem is well posed: same minimiser as the oracle, 1 mm bar."""
+    the latter, k_lm_step<4>), on two cameras so that the problem is well posed: same minimiser as the oracle, 1 mm bar.
+    Last case: another size of both models, as the reference's grid search fits them (3 components, window 2, plain least squares:
+    priors.fit_priors, tests/golden/priors_k3_w2_dense.npz)."""
+    import os
     from cheetah_pose_estimation_amd import priors
     sk = skeleton.build_skeleton("phantom", 24)
-    pr = priors.load_priors(pose=which in ("pose", "both"), motion=which in ("motion", "both"))
+    if which == "both-k3-w2-dense":
+        pr = priors.load_priors(path=os.path.join(os.path.dirname(__file__), "golden", "priors_k3_w2_dense.npz"))
+        assert pr.gmm_k == 3 and pr.lr_window == 2
+    else:
+        pr = priors.load_priors(pose=which in ("pose", "both"), motion=which in ("motion", "both"))
     cam2 = (abi.Camera * 2)(cams6[0], cams6[1])
     opts = abi.default_options()
     h = gpu_handle_factory(sk, cam2, opts, pr)

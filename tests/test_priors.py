@@ -5,6 +5,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 
 from cheetah_pose_estimation_amd import abi, priors, skeleton, synth
 
@@ -74,3 +75,40 @@ def test_oracle_prior_terms_on_dataset_rows(oracle, cams6):
         fm = oracle.objective(sk, cam1, opts, pr, oracle.move_coordinate(sk, qc, n, k, -1e-6), meas, weight)[0]
         fd = (fp - fm) / 2e-6
         assert abs(fd - g[n * 28 + k]) < 1e-4 * max(1.0, abs(fd))
+
+
+G2_PATH = os.path.join(os.path.dirname(__file__), "golden", "priors_k3_w2_dense.npz")
+
+
+def test_second_size_of_both_models_matches_sklearn(oracle):
+    """the reference's grid search varies the number of mixture components and the window (run_dataset.py:814-915): 3 components, window 2, plain
+    least squares (sparse_solution=False) as fitted by the package's own priors.fit_priors; the packed numbers against scikit-learn's evaluations of
+    independently fitted models (tools/fit_priors.py)"""
+    G2 = np.load(G2_PATH)
+    pr = priors.load_priors(path=G2_PATH)
+    assert pr.gmm_k == 3 and pr.gmm_dim == 22 and pr.lr_window == 2
+    for x, lp in zip(G2["gmm_x"], G2["gmm_logpdf"]):
+        f = oracle.lib().cpo_gmm_cost(C.byref(pr), np.ascontiguousarray(x).ctypes.data_as(C.POINTER(C.c_double)), None)
+        assert abs(f - (-np.log(np.exp(lp) + 1e-12))) < 1e-9 * max(1.0, abs(lp))
+    coef = np.array([[pr.lr_coef[p][j] for j in range(2 * 28)] for p in range(28)])
+    assert np.abs(G2["lr_X"] @ coef.T + np.array(pr.lr_b[:28]) - G2["lr_pred"]).max() < 1e-10
+    assert np.count_nonzero(coef) > 0.9 * coef.size                                   # dense: no lasso
+
+
+REF_TABLE = "/root/reference/models/data-driven/dataset_full_pose.csv"
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_TABLE), reason="the reference's pose table is not on this machine")
+def test_fit_priors_repeats_the_packaged_fit_and_refuses_what_the_solver_cannot_hold(tmp_path):
+    """priors.fit_priors with the defaults is the packaged file, number for number (same recipe, deterministic); sizes outside cpe_priors are refused
+    with the reason; a fitted size is cached"""
+    path = priors.fit_priors(5, 4, True, dataset=REF_TABLE, cache_dir=str(tmp_path))
+    a, b = np.load(path), np.load(os.path.join(os.path.dirname(priors.__file__), "data", "priors_full_pose.npz"))
+    assert all(np.array_equal(a[k], b[k]) for k in b.files)
+    assert priors.fit_priors(5, 4, True, dataset="/nonexistent.csv", cache_dir=str(tmp_path)) == path      # cached: the table is not read again
+    with pytest.raises(NotImplementedError):
+        priors.fit_priors(5, 7, True, dataset=REF_TABLE, cache_dir=str(tmp_path))
+    with pytest.raises(NotImplementedError):
+        priors.fit_priors(9, 4, True, dataset=REF_TABLE, cache_dir=str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        priors.fit_priors(2, 4, True, dataset="/nonexistent.csv", cache_dir=str(tmp_path))

@@ -63,6 +63,21 @@ def main():
     np.savez_compressed(gold, lr_X=X[rows], lr_y=y[rows], lr_pred=lr.predict(X[rows]), gmm_x=Xg[rows],
                         gmm_logpdf=gmm.score_samples(Xg[rows]))
     print("wrote", gold)
+    # a second size (the reference's grid search varies both, run_dataset.py:814-915): 3 components, window 2, plain least squares -- fitted by the
+    # PACKAGE's own priors.fit_priors, with scikit-learn's evaluations of independently fitted models beside the numbers
+    sys.path.insert(0, ROOT)
+    from cheetah_pose_estimation_amd import priors as P
+    import tempfile
+    from sklearn.linear_model import LinearRegression
+    path = P.fit_priors(3, 2, False, dataset=os.path.join(REF, "dataset_full_pose.csv"), cache_dir=tempfile.mkdtemp())
+    z = dict(np.load(path))
+    X2, y2 = supervised_xy(df, 2)
+    lr2 = LinearRegression().fit(X2, y2)
+    gmm2 = GaussianMixture(n_components=3, random_state=42, max_iter=20000).fit(Xg)
+    rows2 = np.arange(0, X2.shape[0], 97)[:12]
+    gold2 = os.path.join(ROOT, "tests", "golden", "priors_k3_w2_dense.npz")
+    np.savez_compressed(gold2, lr_X=X2[rows2], lr_pred=lr2.predict(X2[rows2]), gmm_x=Xg[rows2], gmm_logpdf=gmm2.score_samples(Xg[rows2]), **z)
+    print("wrote", gold2)
 
 
 if __name__ == "__main__":
