@@ -30,7 +30,7 @@ def test_algorithmic_bytes_and_traffic_record():
     assert 2.5e5 < b.lm_flops_per_frame_iteration() < 3.5e5
     assert b.HBM_PEAK == 8.0e12
     t = b.pmc_traffic(2048, 200, 6, 25)
-    with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:      # the newest round's record wins (bounded workload: scaled per frame)
+    with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:      # the newest round's record wins (bounded workload: scaled per frame)
         rec = json.load(f)
     per_frame = rec["kernels"]["k_resjac<false"]["total_corrected"] / rec["frames_per_launch"]
     assert abs(t - per_frame * 2048 * 200) < 1e-6 * t and 0.9 < t / (32160 * 2048 * 200) < 1.1
