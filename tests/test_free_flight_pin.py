@@ -78,3 +78,81 @@ def test_contact_rules_hold_in_the_stored_physics_results(oracle, fixture):
     # control: the same windows moved by five frames catch the paws in the air
     sh = np.roll(on, 5, axis=0); sh[:5] = False
     assert np.median(speed[sh]) > 2.0 * np.median(speed[on])
+
+
+def _stance_by_speed(P, fps, limit=3.0):
+    v = np.zeros_like(P); v[1:] = (P[1:] - P[:-1]) * fps; v[0] = v[1]
+    return np.linalg.norm(v, axis=-1) < limit, v
+
+
+def test_kinetic_dataset_physics_result_obeys_the_mass_model_and_the_contact_rules(oracle):
+    """The same two pins on the KINETIC DATASET (its `-02` skeletons, 200 fps and contact rules had no stored result behind them):
+    `kinetic_dataset/2009_09_07/arabia/trial06/fte_kinetic/cam{1..4}_fte.csv` is the 2D reprojection of what the reference's physics-based stage found
+    (run_kinetic, run_dataset.py:1092-1140).  tools/pin_kinetic_dataset_result.py recovered its joint angles with the trial's cameras held FIXED at what
+    its kinematic result gave (tests/golden/fk_csv_pin_arabia.npz): 4.7e-6 px worst over 50 frames -- by itself a second pin of FK + `arabia-02` table +
+    pinhole projection with no camera freedom.  No contact file of the kinetic dataset is shipped, so stance is read off the result: a hock-bottom
+    marker (skeleton.FOOT_MARKERS) slower than 3 m/s (swing: 6 - 27 m/s) -- four windows of 9 - 11 frames, one per foot.  Then
+      * all 39 stance positions lie within 12.4 mm of ONE plane (rms 4.4 mm): the kinetic dataset's `foot_height` tolerance is 0.03 (acinoset_opt.py:783-790);
+      * inside the windows the marker moves along the plane's normal at 0.15 m/s (median), never faster than 1 m/s: `foot_z_vel <= 1` (:807-810, :864-866);
+      * in the aerial phase between the fore and the hind stances the centre of mass of THIS repository's `arabia-02` mass table falls with 9.9 m/s^2
+        on average (second differences at 200 fps, six frames, 9.08 ... 10.77), 7 degrees from the normal of that plane; with the mass spread evenly
+        over the links it 'falls' with 22 - 93 m/s^2."""
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "kinetic_pin_arabia.npz"))
+    assert float(Z["worst_px"]) < 1e-5 and float(Z["fps"]) == 200.0 and Z["q"].shape == (50, 54)
+    sk = skeleton.build_skeleton("arabia-02", 24, kinetic_dataset=True)
+    q, fps = Z["q"], float(Z["fps"])
+    feet = [skeleton.MARKERS.index(m) for m in skeleton.FOOT_MARKERS]
+    P = oracle.markers(sk, q)[:, feet]
+    st, v = _stance_by_speed(P, fps)
+    runs = []
+    for k in range(4):
+        on = np.nonzero(st[:, k])[0]
+        assert 8 <= len(on) <= 12 and on[-1] - on[0] == len(on) - 1            # one contiguous window per foot
+        runs.append((on[0], on[-1]))
+    pts = P[st]
+    c = pts.mean(0)
+    n = np.linalg.svd(pts - c)[2][-1]
+    n = n if n[2] > 0 else -n
+    h = (P - c) @ n
+    assert np.abs(h[st]).max() < 0.02 and np.sqrt((h[st] ** 2).mean()) < 0.008          # inside the 0.03 of the kinetic dataset
+    assert np.median(h[~st]) > 0.1                                                      # swing: well above
+    inner = st.copy()
+    for k, (a, b) in enumerate(runs):
+        inner[a, k] = inner[b, k] = False                                               # the touch-down and lift-off frames carry the swing's speed
+    vn = v @ n
+    assert np.abs(vn[inner]).max() < 1.0 and np.median(np.abs(vn[inner])) < 0.3
+    # aerial phase: no foot in stance within two frames
+    anyst = st.any(1)
+    N = len(q)
+    fl = [m for m in range(3, N - 3) if not anyst[m - 2:m + 3].any()]
+    assert len(fl) >= 4
+    com = oracle.com(sk, q)
+    acc = (com[2:] - 2.0 * com[1:-1] + com[:-2]) * fps ** 2
+    A = acc[[m - 1 for m in fl]]
+    mean = A.mean(0)
+    assert abs(np.linalg.norm(mean) - G) < 0.03 * G, np.linalg.norm(mean)
+    assert np.abs(np.linalg.norm(A, axis=1) - G).max() < 0.11 * G                       # 9.08 ... 10.77: second differences at 200 fps
+    assert np.degrees(np.arccos(np.clip(-mean @ n / np.linalg.norm(mean), -1, 1))) < 10.0
+    sku = skeleton.build_skeleton("arabia-02", 24, kinetic_dataset=True)
+    total = sum(sku.mass[i] for i in range(sku.n_links))
+    for i in range(sku.n_links):
+        sku.mass[i] = total / sku.n_links
+    cu = oracle.com(sku, q)
+    au = ((cu[2:] - 2.0 * cu[1:-1] + cu[:-2]) * fps ** 2)[[m - 1 for m in fl]]
+    assert np.linalg.norm(au, axis=1).min() > 2.0 * G
+    assert abs(np.linalg.norm(mean) * (120.0 / 200.0) ** 2 - G) > 0.5 * G               # the frame rate is part of the statement
+
+
+def test_last_stage_of_the_kinetic_dataset_driver_is_reproduced_in_2d(oracle):
+    """`fte_grf/cam{1..4}_fte.csv` of the same trial (module-level estimate_grf, run_dataset.py:1138): angles recovered with the same fixed cameras to
+    4.3e-6 px; FK + `arabia-02` + pinhole reproduce the stored pixels through the oracle"""
+    from test_fk_pin import _cams_pinhole
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "kinetic_pin_arabia_grf.npz"))
+    assert float(Z["worst_px"]) < 1e-5
+    sk = skeleton.build_skeleton("arabia-02", 24, kinetic_dataset=True)
+    cams = _cams_pinhole(Z)
+    pos = oracle.markers(sk, Z["q"])
+    uv = Z["uv"]
+    seen = ~np.isnan(uv).any(-1)
+    got = np.array([[[oracle.project(cams[c], pos[m, l]) for l in range(24)] for c in range(4)] for m in range(len(pos))])
+    assert np.abs(got - uv)[seen].max() < 1e-4
