@@ -464,6 +464,11 @@ static cpe_status create_impl(cpe_handle* h, const cpe_skeleton* skel, const cpe
             for (int k = 0; k <= W; k++)
                 for (int ta = k; ta <= W; ta++)
                     for (int e = 0; e < nu * nu; e++) P.lr_HI[k][e] += P.lr_PK[ta][ta - k][e];
+            for (int f = 0; f < W * nu; f++) {
+                bool any = false;
+                for (int p2 = 0; p2 < nu; p2++) { P.lr_coefT[f][p2] = priors->lr_coef[p2][f]; any = any || priors->lr_coef[p2][f] != 0.0; }
+                if (any) P.lr_feat[P.lr_nf++] = (uint8_t)f;
+            }
         }
         HIPCHK(hipMalloc(&h->pri, sizeof(DevPriors)));
         HIPCHK(hipMemcpy(h->pri, &P, sizeof(DevPriors), hipMemcpyHostToDevice));
@@ -1182,13 +1187,18 @@ static cpe_status ensure_kws(cpe_handle* h, int B, int N) {
     return CPE_OK;
 }
 
-// one evaluation pass of the physics terms on the evaluated buffer (after k_frame_normal)
+// one evaluation pass of the physics terms on the evaluated buffer (after k_frame_normal): rows, node forces, cost
 static void launch_dyn_eval(cpe_handle* h, int N, int first, size_t Fw, const int32_t* stance, const int* act, const int* n_act, int slots) {
     const unsigned gf = (unsigned)((size_t)slots * N);
     prof_begin(h, 5);
     hipLaunchKernelGGL(k_dyn_eval, dim3(gf), dim3(KIN_THREADS), lds_kin_eval(), h->stream, h->dm, h->dk, h->st, N, first, Fw, h->qbuf, stance, h->fbuf, h->kmu, h->costbuf,
                        h->Jbuf, h->Abuf, h->pieces, h->pmeta, h->dstat, h->slackb, act, n_act);
     prof_end(h);
+}
+// Jacobian and second-order pieces of the CURRENT iterate -- after the accept step, and only for sequences whose iterate is new: a rejected trial
+// costs its evaluation only (a quarter to a third of the iterations of a physics-based solve are rejections)
+static void launch_dyn_pieces(cpe_handle* h, int N, int first, size_t Fw, const int* act, const int* n_act, int slots) {
+    const unsigned gf = (unsigned)((size_t)slots * N);
     prof_begin(h, 10);
     hipLaunchKernelGGL(k_dyn_jac, dim3(gf), dim3(KJ_THREADS), sizeof(double) * KJ_DOUBLES, h->stream, h->dm, h->dk, h->st, N, first, Fw, h->qbuf, h->fbuf, h->Jbuf, act, n_act);
     prof_end(h);
@@ -1272,6 +1282,7 @@ static cpe_status solve_kinetic_impl(cpe_handle* h, const cpe_kinetic_options* o
         hipLaunchKernelGGL((k_lm_step<3, 1>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
                            h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, nullptr, act, n_act, 2, nullptr, h->dgbuf);
         prof_end(h);
+        launch_dyn_pieces(h, N, 0, Fw, act, n_act, slots);        // (`which` = 0 also in the first pass: the accept step has just marked every sequence new)
         prof_begin(h, 9);
         hipLaunchKernelGGL(k_dyn_schur, dim3(gf), dim3(KIN_THREADS), lds_kin_schur(), h->stream, h->dk, h->st, N, Fw, h->pieces, h->pmeta, h->fbuf, h->kmu, stance, h->Tbuf, act, n_act);
         prof_end(h);
@@ -1388,6 +1399,7 @@ cpe_status cpe_eval_kinetic_nodes(cpe_handle* h, const cpe_kinetic_options* opt,
     hipLaunchKernelGGL(FRAME_NORMAL(h->gmm_k == 0), dim3((unsigned)F), dim3(WAVE), lds_normal(m, h->gmm_k, h->gmm_dim), h->stream, h->dm, h->st, N, 1, F, h->qbuf, meas, weight,
                        h->gbuf, h->Bbuf, h->costbuf, h->mu, h->gambuf, h->pri, nullptr, nullptr, ShutterArgs{nullptr, nullptr, nullptr});
     launch_dyn_eval(h, N, 1, F, stance, nullptr, nullptr, B);
+    launch_dyn_pieces(h, N, 1, F, nullptr, nullptr, B);
     HIPCHK(hipGetLastError());
     if (f) HIPCHK(hipMemcpyAsync(f, h->fbuf, sizeof(double) * F * KIN_LS, hipMemcpyDeviceToDevice, h->stream));
     if (stat) HIPCHK(hipMemcpyAsync(stat, h->dstat, sizeof(double) * F * KIN_STAT, hipMemcpyDeviceToDevice, h->stream));

@@ -139,6 +139,11 @@ struct DevPriors {
     cpe_priors p;
     double lr_PK[CPE_MAX_WINDOW + 1][CPE_MAX_WINDOW + 1][CPE_NX * CPE_NX];
     double lr_HI[CPE_MAX_WINDOW + 1][CPE_NX * CPE_NX];
+    // the input features (lag, coordinate) that ANY output of the motion model uses -- the multi-task lasso of the reference keeps 36 of 112 -- in
+    // ascending order, and the coefficients transposed (output index fastest: consecutive lanes read consecutive words)
+    int32_t lr_nf, _pad_nf;
+    uint8_t lr_feat[CPE_MAX_WINDOW * CPE_NX];
+    double lr_coefT[CPE_MAX_WINDOW * CPE_NX][CPE_NX];
 };
 
 // per-sequence Levenberg-Marquardt state (device global memory)
@@ -150,7 +155,7 @@ struct SeqState {
     int32_t outer;      // augmented-Lagrangian multiplier updates done
     int32_t al_pending; // 1: the next k_frame_normal updates the multipliers at the current iterate
     int32_t back_pending; // 1: k_lm_step has factored and left z; k_lm_back still has to solve and write the trial iterate
-    int32_t _pad;
+    int32_t fresh;      // 1: the current iterate is new since its second-order pieces were last built (accepted step, first evaluation, multiplier update)
     double lambda, nu, cost_cur, pred, maxstep, maxviol;
     double terms[5];    // meas, model, bound, pose, motion at the current iterate
 };
