@@ -404,6 +404,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10, help="untimed launches; the clocks of an idle MI355X need ~10 launches (30 ms) to ramp")
+    ap.add_argument("--preheat", type=float, default=1.5, help="seconds of sustained untimed launches before the warm-up: an idle MI355X needs ~1 s of load to reach its steady memory rate")
     ap.add_argument("--batch", type=int, default=2048, help="sequences per GPU for the residual+Jacobian pass")
     ap.add_argument("--solve-batch", type=int, default=8192, help="sequences per GPU for the solve timing (8 MB of solver workspace each: 64 GB of the 288 GB)")
     ap.add_argument("--markers", type=int, default=25)
@@ -507,6 +508,18 @@ def main():
         hh.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
+    # Steady state first.  In a fresh process this store-bound kernel can run at 2.73 ms per launch for about its first second and at 2.43 ms from then
+    # on, while the build that computes J without storing it takes 1.85 ms either way (tools/ab_resjac_box.py on three boxes: 20 launches after 3
+    # warm-up launches 2.72 - 2.74 ms, 400 launches in a row 2.75 ms on average, 20 launches after 400 warm-up launches 2.44 ms; a second handle in the
+    # same process 2.43 - 2.47 ms).  It is the memory side that settles -- whether clocks or the driver's background work on freshly allocated memory
+    # was not established -- and rounds 1 - 2 had read it as slow and fast boxes.  `--preheat` seconds of the same launches, untimed, come before the
+    # W warm-up launches; the line states them.
+    n_heat, t_heat = 0, time.perf_counter()
+    while time.perf_counter() - t_heat < args.preheat:
+        for _ in range(25):
+            h.eval_resjac(t["q_true"], t["meas"], t["weight"], r, J, eps, None)
+        h.synchronize()
+        n_heat += 25
     for _ in range(args.warmup):
         h.eval_resjac(t["q_true"], t["meas"], t["weight"], r, J, eps, None)
     h.synchronize()
@@ -644,6 +657,7 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "preheat": {"seconds": args.preheat, "launches": n_heat, "note": "untimed launches of the same kernel before the warm-up: steady memory rate of the device (tools/ab_resjac_box.py)"},
             "config": {"workload": "cfg2: synthetic 200-frame x 6-cam x 25-marker sequences, phantom skeleton, const-accel model",
                        "frames": N, "cams": C, "markers": L, "sequences_per_gpu": B, "parallelism": f"shard{world} (independent sequences, no collective)"},
             "solves": solves, "solves_cfg3": cfg3, "solves_cfg4": cfg4, "markers24": l24,

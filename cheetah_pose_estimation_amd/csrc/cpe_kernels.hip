@@ -313,7 +313,11 @@ __global__ __launch_bounds__(WAVE * NW, (OCC * NW) / 4) void k_resjac(const DevM
                     v2d val;
                     val.x = g0.x * dp0[i] + g0.y * dp1[i] + g1.x * dp2[i];
                     val.y = g1.y * dp0[i] + g2.x * dp1[i] + g2.y * dp2[i];
+#ifdef CPE_RJ_NOSTORE       // diagnostic build only (profiles/r01_resjac_ablation.md): J computed, not stored -- the compute floor of the box
+                    if (val.x == 1.2345e300) Jf[c * S + s] = make_double2(val.x, val.y);
+#else
                     __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(&Jf[c * S + s]));
+#endif
                 }
             }
         }
