@@ -512,7 +512,7 @@ def main():
     # on, while the build that computes J without storing it takes 1.85 ms either way (tools/ab_resjac_box.py on three boxes: 20 launches after 3
     # warm-up launches 2.72 - 2.74 ms, 400 launches in a row 2.75 ms on average, 20 launches after 400 warm-up launches 2.44 ms; a second handle in the
     # same process 2.43 - 2.47 ms).  It is the memory side that settles -- whether clocks or the driver's background work on freshly allocated memory
-    # was not established -- and rounds 1 - 2 had read it as slow and fast boxes.  `--preheat` seconds of the same launches, untimed, come before the
+    # was not established.  (Boxes differ as well: one ran 2.64 ms with and without this.)  `--preheat` seconds of the same launches, untimed, come before the
     # W warm-up launches; the line states them.
     n_heat, t_heat = 0, time.perf_counter()
     while time.perf_counter() - t_heat < args.preheat:
