@@ -383,6 +383,25 @@ def pmc_traffic(B, N, C, L, kernel="k_resjac"):
     return best
 
 
+def pmc_valu_active(kernel="k_resjac<false"):
+    """SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of `kernel` from the newest committed SQ pass (profiles/rNN_pmc_sq.csv, tools/profile_round.sh): the share
+    of a wave's cycles with a vector instruction in flight (SURVEY 8d asks for it beside the achieved GB/s).  None if no such record."""
+    import csv
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_sq.csv"))):
+        try:
+            with open(f, newline="") as fh:
+                rows = [r_ for r_ in csv.DictReader(fh) if kernel in r_["kernel"]]
+            v = {r_["counter"]: float(r_["mean_per_dispatch"]) for r_ in rows}
+            if v.get("SQ_WAVE_CYCLES"):
+                best = {"valu_active_frac": v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_WAVE_CYCLES"], "wait_any_frac": v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"],
+                        "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return best
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent never imports torch
     or touches the GPU), one per GPU, rendezvous on 127.0.0.1; rank 0 prints the JSON line.  Returns the worst exit status."""
@@ -662,7 +681,7 @@ def main():
                        "frames": N, "cams": C, "markers": L, "sequences_per_gpu": B, "parallelism": f"shard{world} (independent sequences, no collective)"},
             "solves": solves, "solves_cfg3": cfg3, "solves_cfg4": cfg4, "markers24": l24,
             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                         "traffic": pmc_traffic(B, N, C, L), "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
+                         "traffic": pmc_traffic(B, N, C, L), "kernel": "k_resjac<false>", "kernel_ms": kern_ms, "bytes_per_frame": bpf, "sq": pmc_valu_active()},
         }
         if ms_cost is not None:
             bc = resjac_bytes_per_frame(C, L, S, sk.nq, True)
