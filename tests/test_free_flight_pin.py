@@ -132,7 +132,7 @@ def test_kinetic_dataset_physics_result_obeys_the_mass_model_and_the_contact_rul
     mean = A.mean(0)
     assert abs(np.linalg.norm(mean) - G) < 0.03 * G, np.linalg.norm(mean)
     assert np.abs(np.linalg.norm(A, axis=1) - G).max() < 0.11 * G                       # 9.08 ... 10.77: second differences at 200 fps
-    assert np.degrees(np.arccos(np.clip(-mean @ n / np.linalg.norm(mean), -1, 1))) < 10.0
+    assert np.degrees(np.arccos(np.clip(-mean @ n / np.linalg.norm(mean), -1, 1))) < 5.0
     sku = skeleton.build_skeleton("arabia-02", 24, kinetic_dataset=True)
     total = sum(sku.mass[i] for i in range(sku.n_links))
     for i in range(sku.n_links):
@@ -141,6 +141,19 @@ def test_kinetic_dataset_physics_result_obeys_the_mass_model_and_the_contact_rul
     au = ((cu[2:] - 2.0 * cu[1:-1] + cu[:-2]) * fps ** 2)[[m - 1 for m in fl]]
     assert np.linalg.norm(au, axis=1).min() > 2.0 * G
     assert abs(np.linalg.norm(mean) * (120.0 / 200.0) ** 2 - G) > 0.5 * G               # the frame rate is part of the statement
+    # The world frame of these pins was fixed by the joint-angle bounds of the KINEMATIC result alone (tools/reframe_kinetic_pin.py, tests/test_fk_pin.py).
+    # Three independent things agree in it: the physics-based result obeys the same bounds (to IPOPT's tolerance), the ground the paws touch is
+    # horizontal, and the centre of mass falls along -z.
+    viol = 0.0
+    for b in range(sk.n_bounds):
+        ia, ib = sk.bound_a[b], sk.bound_b[b]
+        dlt = q[:, ia] - (q[:, ib] if ib >= 0 else 0.0)
+        dlt = (dlt + np.pi) % (2 * np.pi) - np.pi
+        viol = max(viol, float(np.maximum(dlt - sk.bound_up[b], sk.bound_lo[b] - dlt).max()))
+    assert viol < 2e-3, viol                                                            # measured 5.4e-4 (fte_kinetic), 9.9e-4 (fte_grf)
+    assert np.degrees(np.arccos(np.clip(n[2], -1, 1))) < 2.0                            # stance plane: 1.0 degree from z
+    assert np.degrees(np.arccos(np.clip(-mean[2] / np.linalg.norm(mean), -1, 1))) < 3.0 # free fall: 1.7 degrees from -z
+    assert P[st][:, 2].max() - P[st][:, 2].min() < 0.03                                 # all stance heights within 24 mm in z
 
 
 def test_last_stage_of_the_kinetic_dataset_driver_is_reproduced_in_2d(oracle):
