@@ -198,6 +198,10 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             }
         }
     m.ns = nq + m.nrev;
+    for (int k = 0; k < nu; k++) {
+        const int r = m.rev_of_u[k];
+        m.ucost[k] = r < 0 ? m.indep[k] : ((3 + 3 * m.rev_body[r] + 1) | (nq + r + 1) << 8);      // trunk: its Euler angle; leg: theta_B + alpha_r
+    }
     if (m.nrev > LM_MAX_REV) return fail(CPE_BAD_ARG, "more than 12 leg links");
     for (int k = 0; k < nu; k++) if (m.bodyang_legs_n[k] > LM_MAX_LEGS) return fail(CPE_BAD_ARG, "more than 6 leg links on one body");
     for (int r = 0; r < m.nrev; r++) m.ucoord_src[m.rev_u[r]] = nq + r;
@@ -386,7 +390,9 @@ static cpe_status build_model(const cpe_skeleton* s, const cpe_camera* cams, int
             return fail(CPE_BAD_ARG, "bounds must act on independent dofs");
         m.bound_ua[bnd] = m.u_of_q[a]; m.bound_ub[bnd] = bb < 0 ? -1 : m.u_of_q[bb];
         m.bound_lo[bnd] = s->bound_lo[bnd]; m.bound_up[bnd] = s->bound_up[bnd];
-        m.bnd_q[bnd] = a | ((bb + 1) << 8);
+        // (state index of the value, + 1 of the second addend or 0) for each side: a leg pitch is theta_B + alpha (ucost)
+        const int ca = m.ucost[m.u_of_q[a]], cb = bb < 0 ? 0 : m.ucost[m.u_of_q[bb]];
+        m.bnd_q[bnd] = (ca & 255) | (bb < 0 ? 0 : ((cb & 255) + 1) << 8) | ((ca >> 8) & 255) << 16 | (bb < 0 ? 0 : ((cb >> 8) & 255)) << 24;
     }
     return CPE_OK;
 }

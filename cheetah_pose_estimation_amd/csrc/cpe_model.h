@@ -46,6 +46,10 @@ struct DevModel {
     int32_t joint_dep0[CPE_MAX_JOINTS];     // first dependent row of this joint (phi; psi = +1 if revolute)
 
     int32_t indep[CPE_NX];
+    // COST PITCH of the leg links: the terms of the objective that act on the Euler pitch of a leg link -- constant-acceleration cost, joint
+    // ranges, learned priors -- take theta_B + alpha_c (pitch of the body the leg hangs from + the leg angle about the body's y axis): the reference's
+    // variable for an unrolled trunk, smooth through +-90 degrees.  ucost[k] = s0 | (s1 + 1) << 8: value of weighted coordinate k = state[s0] (+ state[s1]).
+    int32_t ucost[CPE_NX];
     int32_t u_of_q[CPE_MAX_NQ];             // -1 for dependent dofs
     int32_t dep_of_q[CPE_MAX_NQ];           // -1 for independent dofs
     double motion_w_u[CPE_NX];

@@ -888,7 +888,7 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
     opts = options if options is not None else abi.default_options(scene.fps)
     opts.h = 1.0 / scene.fps
     if options is None:
-        opts.tol_cost, opts.max_iter = 1e-6, 600           # the physics term is stiff: see DESIGN.md 2b (the reference stops IPOPT at Tol = 1e-3)
+        opts.tol_cost, opts.max_iter = 1e-6, 1500          # the physics term is stiff: see DESIGN.md 2b (the reference stops IPOPT at Tol = 1e-3; a monocular start with a missed contact window has taken 1 200 iterations)
     ko = kinetic_options if kinetic_options is not None else abi.default_kinetic_options(skeleton.dyn_options(est.name), scene.fps, params.kinetic_dataset)
     if not no_slip and not joint_estimation:
         ko.slip_max = 0.0                                                            # `no_slip` guards the rules of the prescribed-force branch only (acinoset_opt.py:855-866);
@@ -986,7 +986,7 @@ def estimate_grf(estimator: CheetahEstimator, solver_output: bool = True, out_di
     opts = options if options is not None else abi.default_options(scene.fps)
     opts.h = 1.0 / scene.fps
     if options is None:
-        opts.tol_cost, opts.max_iter = 1e-6, 600
+        opts.tol_cost, opts.max_iter = 1e-6, 1500
     ko = kinetic_options if kinetic_options is not None else abi.default_kinetic_options(skeleton.dyn_options(est.name), scene.fps, True)
     if kinetic_options is None:
         ko.foot_height_tol = 0.03                                                    # foot_height in [-0.03, 0.03] during a contact (:1010-1012)

@@ -117,6 +117,17 @@ def legs_from_alpha(sk: abi.Skeleton, q: np.ndarray, alpha: np.ndarray) -> np.nd
     return q
 
 
+def cost_view_numpy(sk: abi.Skeleton, q: np.ndarray) -> np.ndarray:
+    """What the solver's cost terms see of an Euler trajectory q[..., nq] ('cost pitch'): the pitch slot of every leg link holds
+    theta_B + alpha_c -- pitch of the body the leg hangs from + the leg's angle about the body's y axis (alpha_c from R_B^T R_c) -- instead of the
+    Euler pitch of the link's own (principal) triple.  Equal to the reference's variable for an unrolled trunk, smooth through +-90 degrees."""
+    qc = q.copy()
+    for c, B in leg_layout(sk):
+        M = np.einsum("...ji,...jk->...ik", rot_zyx(q[..., 3 + 3 * B:6 + 3 * B]), rot_zyx(q[..., 3 + 3 * c:6 + 3 * c]))
+        qc[..., 3 + 3 * c + 1] = q[..., 3 + 3 * B + 1] + np.arctan2(M[..., 0, 2], M[..., 0, 0])
+    return qc
+
+
 # ---------------------------------------------------------------------------------------------------
 def look_at_camera(pos, target, fx, fy, cx, cy, D, model=abi.CAM_FISHEYE, mult=1.0) -> abi.Camera:
     pos, target = np.asarray(pos, float), np.asarray(target, float)

@@ -578,7 +578,22 @@ static void state_jacobian(const ctx_t* x, const double* st, double* Zp) {
     }
 }
 
-/* cost terms for one frame; returns meas cost, *cb bound-penalty cost, *cp pose-prior cost */
+/* COST VIEW of a frame's Euler angles: the terms of the objective that act on the Euler pitch of a leg link -- constant-acceleration cost,
+ * joint ranges, learned priors -- take theta_B + alpha_c (pitch of the body the leg hangs from + the leg angle about the body's y axis): the reference's
+ * variable for an unrolled trunk, smooth through +-90 degrees (the state keeps the principal triple: forward kinematics, outputs, physics terms).
+ * qc [nq], Zc [nq][nu] (if Z): copies of the state's Euler part / of Z' with the leg-pitch entries / rows replaced. */
+static void cost_view(const ctx_t* x, const double* st, const double* Z, double* qc, double* Zc) {
+    const cpe_skeleton* s = x->s; int nq = x->nq, nu = x->nu;
+    memcpy(qc, st, sizeof(double) * nq);
+    if (Z) memcpy(Zc, Z, sizeof(double) * nq * nu);
+    for (int r = 0; r < x->nrev; r++) {
+        int c = s->joint_child[x->rev_joint[r]], B = x->rev_body[r], p = 3 + 3 * c + 1, pb = 3 + 3 * B + 1;
+        qc[p] = st[pb] + st[nq + r];
+        if (Z) for (int k = 0; k < nu; k++) Zc[p * nu + k] = Z[pb * nu + k] + (x->rev_of_u[k] == r ? 1.0 : 0.0);
+    }
+}
+
+/* cost terms for one frame; returns meas cost, *cb bound-penalty cost, *cp pose-prior cost.  qn must point into a STATE (Euler part | leg angles). */
 static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* [nq][nu], needed iff g */, const double* meas, const double* weight,
                           const double* mu, double* g, double* Bm, double* cb, double* cp, double* viol_out,
                           const double* x1, const double* x2 /* base positions of frames n-1, n-2 (shutter delay, n >= 2), or NULL */,
@@ -587,6 +602,9 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
     double pos[CPE_MAX_MARKERS * 3];
     double* dpos = NULL; const double* Z = Zp; double* dpu = NULL;
     int want = g != NULL;
+    double qc[CPE_MAX_NQ];
+    double* Zc = want ? (double*)malloc(sizeof(double) * nq * nu) : NULL;
+    cost_view(x, qn, want ? Zp : NULL, qc, Zc);
     if (want) {
         dpos = (double*)malloc(sizeof(double) * L * 3 * nq);
         dpu = (double*)malloc(sizeof(double) * L * 3 * nu);
@@ -646,7 +664,7 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
     for (int b = 0; b < s->n_bounds; b++) {
         int ia = s->bound_a[b], ib = s->bound_b[b];
         double kp = x->o->bound_penalty;
-        double v = qn[ia] - (ib >= 0 ? qn[ib] : 0.0);
+        double v = qc[ia] - (ib >= 0 ? qc[ib] : 0.0);
         double mu_up = mu ? mu[2 * b] : 0.0, mu_lo = mu ? mu[2 * b + 1] : 0.0;
         double t_up = mu_up + kp * (v - s->bound_up[b]), t_lo = mu_lo + kp * (s->bound_lo[b] - v);
         if (v - s->bound_up[b] > vmax) vmax = v - s->bound_up[b];
@@ -656,7 +674,7 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
         if (want && (pu > 0 || pl > 0)) {
             /* v is a difference of Euler angles; its gradient w.r.t. the reduced coordinates is a difference of rows of Z' */
             double gv = pu - pl, hv = kp * ((pu > 0) + (pl > 0)), dv[CPE_NX];
-            for (int k = 0; k < nu; k++) dv[k] = Z[ia * nu + k] - (ib >= 0 ? Z[ib * nu + k] : 0.0);
+            for (int k = 0; k < nu; k++) dv[k] = Zc[ia * nu + k] - (ib >= 0 ? Zc[ib * nu + k] : 0.0);
             for (int k = 0; k < nu; k++) {
                 if (dv[k] == 0.0) continue;
                 g[k] += gv * dv[k];
@@ -670,7 +688,7 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
     if (x->pr && x->pr->gmm_k > 0) {
         double xr[CPE_NX], gr[CPE_NX], Hx[CPE_NX * CPE_NX];
         int D = x->pr->gmm_dim, off = nu - D;
-        cpo_relative_angles(s, qn, xr);
+        cpo_relative_angles(s, qc, xr);
         fp = gmm_eval(x->pr, xr + off, want ? gr : NULL, want ? Hx : NULL);
         if (want) {
             /* x_i = sign_i (q_p - q_ref(p)); d x_i / d u' = sign_i (Z'[p] - Z'[ref]) */
@@ -678,7 +696,7 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
             for (int i = 0; i < D; i++) {
                 int pi = x->indep[off + i];
                 double si = s->rel_ref[pi] < 0 ? 1.0 : s->rel_sign[pi];
-                for (int k = 0; k < nu; k++) Xp[i * nu + k] = si * (Z[pi * nu + k] - (s->rel_ref[pi] < 0 ? 0.0 : Z[s->rel_ref[pi] * nu + k]));
+                for (int k = 0; k < nu; k++) Xp[i * nu + k] = si * (Zc[pi * nu + k] - (s->rel_ref[pi] < 0 ? 0.0 : Zc[s->rel_ref[pi] * nu + k]));
             }
             for (int k = 0; k < nu; k++) {
                 double a = 0;
@@ -698,7 +716,7 @@ static double frame_terms(const ctx_t* x, const double* qn, const double* Zp /* 
         }
     }
     if (cb) *cb = fb; if (cp) *cp = fp;
-    if (want) { free(dpos); free(dpu); }
+    if (want) { free(dpos); free(dpu); free(Zc); }
     return fm;
 }
 
@@ -753,12 +771,15 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
     memset(ct, 0, sizeof(*ct));
     double* gB = g ? (double*)malloc(sizeof(double) * (nu + nu * nu)) : NULL;
     double* Zall = g ? (double*)malloc(sizeof(double) * (size_t)N * nq * nu) : NULL;   /* Z'_n = d q_n / d u'_n */
+    double* Qcv = (double*)malloc(sizeof(double) * (size_t)N * nq);                     /* cost view of every frame (cost_view): what the motion terms act on */
+    double* Zcv = g ? (double*)malloc(sizeof(double) * (size_t)N * nq * nu) : NULL;
     if (g) { memset(g, 0, sizeof(double) * n_tot); memset(ab, 0, sizeof(double) * (size_t)n_tot * (kd + 1)); }
     for (int n = 0; n < N; n++) {
         double* sn = st + (size_t)n * ns;
         state_sync(x, sn);
         double* Zn = g ? Zall + (size_t)n * nq * nu : NULL;
         if (g) state_jacobian(x, sn, Zn);
+        cost_view(x, sn, Zn, Qcv + (size_t)n * nq, g ? Zcv + (size_t)n * nq * nu : NULL);
         double cb, cp, vm;
         double gx6[6];
         int sd = x->tau != NULL && n >= 2;                       /* the displacement acts from node 2 on (include/cpe.h, cpe_solve_shutter) */
@@ -775,7 +796,7 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
             }
         }
     }
-#define Q(n, p) st[(size_t)(n) * ns + (p)]
+#define Q(n, p) Qcv[(size_t)(n) * nq + (p)]
     /* constant-acceleration model on the EULER angles (acinoset_misc.py:639-677): sum_{n>=3} w_p eps_{n,p}^2,
      * eps = third difference / h^2; Gauss-Newton through Z' (exactly quadratic for the trunk coordinates) */
     double ih2 = 1.0 / (x->o->h * x->o->h);
@@ -790,13 +811,13 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
             ct->model += w * e * e;
             if (!g) continue;
             for (int t = 0; t < 4; t++) {
-                const double* Za = Zall + ((size_t)(n - 3 + t) * nq + p) * nu;
+                const double* Za = Zcv + ((size_t)(n - 3 + t) * nq + p) * nu;
                 for (int k = 0; k < nu; k++) {
                     if (Za[k] == 0.0) continue;
                     int ia = (n - 3 + t) * nu + k;
                     g[ia] += 2 * w * e * d3[t] * ih2 * Za[k];
                     for (int t2 = 0; t2 <= t; t2++) {
-                        const double* Zb = Zall + ((size_t)(n - 3 + t2) * nq + p) * nu;
+                        const double* Zb = Zcv + ((size_t)(n - 3 + t2) * nq + p) * nu;
                         for (int k2 = 0; k2 < nu; k2++) {
                             int ib = (n - 3 + t2) * nu + k2;
                             if (ib > ia || Zb[k2] == 0.0) continue;
@@ -813,13 +834,13 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
         double* xs = (double*)malloc(sizeof(double) * N * nu);
         double* Xp = g ? (double*)malloc(sizeof(double) * (size_t)N * nu * nu) : NULL;     /* d x_n / d u'_n */
         for (int n = 0; n < N; n++) {
-            cpo_relative_angles(s, st + (size_t)n * ns, xs + n * nu);
+            cpo_relative_angles(s, Qcv + (size_t)n * nq, xs + n * nu);
             if (g)
                 for (int i = 0; i < nu; i++) {
                     int pi = x->indep[i];
                     double si = s->rel_ref[pi] < 0 ? 1.0 : s->rel_sign[pi];
-                    const double* Za = Zall + ((size_t)n * nq + pi) * nu;
-                    const double* Zr = s->rel_ref[pi] < 0 ? NULL : Zall + ((size_t)n * nq + s->rel_ref[pi]) * nu;
+                    const double* Za = Zcv + ((size_t)n * nq + pi) * nu;
+                    const double* Zr = s->rel_ref[pi] < 0 ? NULL : Zcv + ((size_t)n * nq + s->rel_ref[pi]) * nu;
                     for (int k = 0; k < nu; k++) Xp[((size_t)n * nu + i) * nu + k] = si * (Za[k] - (Zr ? Zr[k] : 0.0));
                 }
         }
@@ -860,6 +881,7 @@ static void seq_eval(const ctx_t* x, int N, int kd, double* st /* [N][ns] states
     ct->total = ct->meas + ct->model + ct->pose + ct->motion + ct->bound;
     if (gB) free(gB);
     if (Zall) free(Zall);
+    free(Qcv); if (Zcv) free(Zcv);
 }
 
 /* Levenberg-Marquardt over the whole trajectory in reduced coordinates (stands where IPOPT is called,
@@ -960,7 +982,9 @@ static cpe_status solve_impl2(const cpe_skeleton* s, const cpe_camera* cams, int
                 for (int n = 0; n < N; n++)
                     for (int b = 0; b < s->n_bounds; b++) {
                         int ia = s->bound_a[b], ib = s->bound_b[b];
-                        double v = qc[(size_t)n * ns + ia] - (ib >= 0 ? qc[(size_t)n * ns + ib] : 0.0);
+                        double qv[CPE_MAX_NQ];
+                        cost_view(&x, qc + (size_t)n * ns, NULL, qv, NULL);          /* the ranges act on the cost view (leg pitch = theta_B + alpha) */
+                        double v = qv[ia] - (ib >= 0 ? qv[ib] : 0.0);
                         double* m2 = mu + ((size_t)n * s->n_bounds + b) * 2;
                         double t_up = m2[0] + o->bound_penalty * (v - s->bound_up[b]), t_lo = m2[1] + o->bound_penalty * (s->bound_lo[b] - v);
                         m2[0] = t_up > 0 ? t_up : 0; m2[1] = t_lo > 0 ? t_lo : 0;

@@ -163,18 +163,17 @@ def test_tikhonov_weight_of_the_node_forces_is_inert(oracle):
     assert rmse < 1e-3 and dtau < 0.05 and dgrf < 0.05
 
 
-def test_principal_triple_on_a_200_fps_gallop_of_the_kinetic_dataset():
-    """Deviation (a) where it is LARGE.  kinetic_dataset/2009_09_07/arabia/trial06 (tests/golden/fk_csv_pin_arabia.npz, in the world frame the joint-angle
-    bounds fix): a 200 fps gallop in which four leg links swing beyond the horizontal (30 of 400 leg-link states with cos(phi) < 0).  The
-    constant-acceleration cost of the stored solution -- third differences / h^2, weights 1 / Q^2 (acinoset_misc.py:639-677) --
+def test_cost_pitch_on_a_200_fps_gallop_of_the_kinetic_dataset():
+    """Deviation (a) where it WAS large, and what replaced it.  kinetic_dataset/2009_09_07/arabia/trial06 (tests/golden/fk_csv_pin_arabia.npz, in the world
+    frame the joint-angle bounds fix): a 200 fps gallop in which four leg links swing beyond the horizontal (30 of 400 leg-link states with cos(phi) < 0).
+    The constant-acceleration cost of the stored solution -- third differences / h^2, weights 1 / Q^2 (acinoset_misc.py:639-677) --
       * along the triple whose roll stays next to the body's (pitch runs past +-90 degrees: the path the reference's variables take from their start
-        at phi = theta = 0):                                                   102.5
-      * along the principal triple this build reads back (pitch turns around at +-90 degrees, roll and yaw jump by pi):   15 420.9, 99 % of it in the
-        pitch of those four links.
-    On this trial the deviation IS the model term: the read-back makes the solver avoid limbs beyond the horizontal and its kinematic solve of such a trial
-    creeps (measured with the CPU checker: no stop within 200 iterations from the stored solution; DESIGN.md 8, first item).  The body-relative triple was
-    built and measured in round 3 (profiles/r03_notes.md) and NOT shipped: with a rolled trunk the two triples are separated by a jump of ~2 x roll where
-    the limb passes the pole, which needs a smooth bridge before the Levenberg-Marquardt loop can live with it."""
+        at phi = theta = 0):                                                                 102.5
+      * along the principal triple rounds 1-2 let the cost terms see (pitch turns around at +-90 degrees):   15 420.9, 99 % of it in those four links
+        -- on such a trial the deviation WAS the model term, and the kinematic solve crept (no stop within 200 iterations from the stored solution);
+      * along the COST PITCH the solver uses since round 3, theta_B + alpha_c (synth.cost_view_numpy):   105.4 -- the reference's variable
+        up to O(roll^2) away from the pole, smooth through it.  (The body-relative triple itself was built and measured too: it jumps by ~2 x roll at
+        the pole and the Levenberg-Marquardt loop parks on the jump, profiles/r03_notes.md.)"""
     Z = np.load(os.path.join(GOLD, "fk_csv_pin_arabia.npz"))
     sk = skeleton.build_skeleton("arabia-02", 24, kinetic_dataset=True)
     q = Z["q"]
@@ -197,9 +196,13 @@ def test_principal_triple_on_a_200_fps_gallop_of_the_kinetic_dataset():
         qb[:, 4 + 3 * c] = th2
         qb[:, 5 + 3 * c] = ps2 + 2 * np.pi * np.round((q[:, 5 + 3 * B] - ps2) / (2 * np.pi))
     assert np.abs(synth.fk_numpy(sk, q)[0] - synth.fk_numpy(sk, qb)[0]).max() < 1e-12       # the same poses
-    cp, cb = cost(q), cost(qb)
-    print(f"\narabia trial06, 200 fps: constant-acceleration cost along the principal triple {cp.sum():.1f}, along the body-relative triple {cb.sum():.1f}; "
-          f"{flips} leg-link states differ; largest pitch {np.abs(qb[:, 4::3]).max():.2f} rad")
+    qv = synth.cost_view_numpy(sk, q)
+    cp, cb, cv = cost(q), cost(qb), cost(qv)
+    print(f"\narabia trial06, 200 fps: constant-acceleration cost along the principal triple {cp.sum():.1f}, along the body-relative triple {cb.sum():.1f}, "
+          f"along the cost pitch {cv.sum():.1f}; {flips} leg-link states differ; largest pitch {np.abs(qb[:, 4::3]).max():.2f} rad; "
+          f"cost pitch - body-relative pitch: max {np.abs(qv[:, 4::3] - qb[:, 4::3]).max():.3f} rad")
     assert flips == 30 and np.abs(qb[:, 4::3]).max() > 1.7
     assert cb.sum() < 150.0 and cp.sum() > 100.0 * cb.sum()
     assert np.sort(cp)[-4:].sum() > 0.99 * cp.sum()
+    assert abs(cv.sum() - cb.sum()) < 0.05 * cb.sum()                                     # 105.4 against 102.5
+    assert np.abs(qv[:, 4::3] - qb[:, 4::3]).max() < 0.12                                 # within ~roll of the reference's variable, at the pole

@@ -45,7 +45,8 @@ def test_full_space_slsqp_agrees_with_reduced_lm(oracle):
             uv, _ = synth.project_numpy(cams3[c], pos)
             s = cams3[c].mult * weight[:, c, :, None] * (uv - meas[:, c])
             f += rho_np(s).sum()
-        eps = (q[3:] - 3 * q[2:-1] + 3 * q[1:-2] - q[:-3]) / h**2
+        qv = synth.cost_view_numpy(sk, q)        # the model term acts on the cost view: leg pitch = theta_B + alpha
+        eps = (qv[3:] - 3 * qv[2:-1] + 3 * qv[1:-2] - qv[:-3]) / h**2
         return f + (wq * eps**2).sum()
 
     def cons(x):
