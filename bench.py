@@ -296,7 +296,7 @@ def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu
     _, kst = hk.solve(T["q_init"], T["meas"], T["weight"], q, dq, ddq, pos, me)          # the kinematic estimate = the warm start
     hk.synchronize(); hk.close()
     q0 = q.clone()
-    opts = abi.default_options(120.0); opts.tol_cost, opts.max_iter = 1e-6, 600
+    opts = abi.default_options(120.0); opts.tol_cost, opts.max_iter = 1e-6, 400      # (the slowest CONVERGING sequence of the batch needs 198 iterations; `converged_frac` states the rest)
     ko = abi.default_kinetic_options(skeleton.dyn_options("phantom"), 120.0)
     h = _lib.Handle(skk, cams, opts, pr_dyn, device=local)
     nm, nf, nc = ko.dyn.n_motors, ko.dyn.n_feet, h.n_constraint_rows()
@@ -329,7 +329,7 @@ def bench_cfg4(torch, _lib, abi, skeleton, synth, dev, local, d4, N, n_cams, cpu
         kern[k] = dict(ms_total=ms.get(k, 0.0), launches=nl.get(k, 0))
     tot = sum(v["ms_total"] for v in kern.values())
     dom = max(("k_dyn_eval", "k_dyn_jac", "k_dyn_assemble", "k_dyn_schur", "k_dyn_gather"), key=lambda k: kern[k]["ms_total"])
-    out = dict(value=B / el, unit="solves/s", workload=f"cfg4: physics-based model, 200 frames x {n_cams} camera(s) x 24 markers, rotary gallop 3 Hz, 12-frame stance, seed 4321 + b"
+    out = dict(value=B / el, unit="solves/s", workload=f"cfg4: physics-based model, 200 frames x {n_cams} camera(s) x 24 markers, rotary gallop 3 Hz, 12-frame stance, seed 4321 + b, at most 400 iterations"
                + (", pose prior, monocular warm start" if n_cams == 1 else ""),
                batch=B, seconds=el, iterations_mean=float(its.mean()), iterations_max=int(its.max()), converged_frac=float((stt == 0).mean()),
                warm_start_converged_frac=float(np.mean([s_.status == 0 for s_ in kst])), max_slack=float(max(k_.max_slack for k_ in ks)),
