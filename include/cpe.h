@@ -200,7 +200,7 @@ cpe_status cpe_project_joints(cpe_handle* h, int32_t B, int32_t N, double* q);
 /* ---- building block of the solver: per-frame terms in the reduced coordinates at the Euler
  * iterate q (leg angles are taken as rotations of their body about its y axis, tails re-projected).
  * Device pointers.  g [B][N][28]; Bm [B][N][28][28] (measurement + bound + pose-prior Gauss-Newton block);
- * cost [B][N][3] = {robust measurement cost, bound term, pose-prior term}; gam [B][N][nrev][4] = d theta_leg / d(alpha, phi_B, theta_B, psi_B);
+ * cost [B][N][3] = {robust measurement cost, bound term, pose-prior term}; gam [B][N][nrev][4] = d (cost pitch of the leg link) / d(alpha, phi_B, theta_B, psi_B) = (1, 0, 1, 0) since round 3;
  * q_out [B][N][nq] = the consistent Euler angles.  gam and q_out may be NULL. */
 /* (per frame, what ASL hands IPOPT for measurement_cost acinoset_misc.py:459-484, the angle bounds cheetah.py:306-352 and
  * gmm_pose_cost acinoset_misc.py:680-714: value, gradient and Hessian block) */
@@ -212,6 +212,11 @@ cpe_status cpe_eval_normal(cpe_handle* h, int32_t B, int32_t N, const double* q,
  * Device pointers.  q_init [B][N][nq] (dependent angles are re-projected), outputs as the reference
  * saves them (acinoset_opt.py:289-361):
  *   q,dq,ddq [B][N][nq] ; positions [B][N][L][3] ; meas_err [B][N][C][L][2] ; stats[B] (HOST pointer)
+ * Leg links: q holds the principal ZYX triple of every link (|pitch| <= pi / 2; the same rotation has the triple (phi + pi, pi - theta, psi + pi), which
+ * is the one the reference's variables are on while a limb is beyond the horizontal).  The three terms of the objective that act on a leg link's pitch
+ * itself -- constant-acceleration cost (acinoset_misc.py:639-677), joint ranges (cheetah.py:306-352), learned priors (acinoset_misc.py:291-336, :680-714)
+ * -- are evaluated on theta_body + alpha_link (the leg's angle about its body's y axis): the reference's variable for an unrolled trunk, smooth through
+ * +-pi / 2 ("cost pitch").
  */
 cpe_status cpe_solve(cpe_handle* h, int32_t B, int32_t N, const double* q_init, const double* meas,
                      const double* weight, double* q, double* dq, double* ddq, double* positions,

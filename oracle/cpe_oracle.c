@@ -525,7 +525,7 @@ static void state_sync(const ctx_t* x, double* st) {
         mat3mul(RB, Ry, Rc);
         double* e = st + 3 + 3 * c;
         double sth = -Rc[6]; if (sth > 1) sth = 1; if (sth < -1) sth = -1;
-        e[1] = asin(sth);                       /* principal pitch: the continuous path of the reference's Euler angles */
+        e[1] = asin(sth);                       /* principal pitch: the STATE's triple (FK, outputs, physics rows); the cost terms see theta_B + alpha, cost_view() */
         e[0] = atan2(Rc[7], Rc[8]);
         e[2] = atan2(Rc[3], Rc[0]);
         e[2] += 2 * M_PI * round((st[3 + 3 * B + 2] - e[2]) / (2 * M_PI));
