@@ -322,7 +322,7 @@ def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_
         n = Zs["q"].shape[0]
         missing = np.isnan(Zs["uv"]).any(-1)
         rs = hs.eval_resjac_host(Zs["q"][None], np.ascontiguousarray(np.nan_to_num(Zs["uv"])[None]), np.ones((1, n, 4, 24)))[0][0]
-        assert np.abs(rs[~missing]).max() < (1e-4 if "arabia" in fx else 5e-3), (fx, np.abs(rs[~missing]).max())      # (tests/test_fk_pin.py on the two levels)
+        assert np.abs(rs[~missing]).max() < (1e-4 if "arabia" in fx else 1e-3), (fx, np.abs(rs[~missing]).max())      # (tests/test_fk_pin.py on the two levels)
 
 
 def test_solve_on_the_real_run_matches_oracle(oracle, gpu_handle_factory):
