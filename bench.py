@@ -233,7 +233,7 @@ def bench_cfg3(torch, _lib, abi, skeleton, synth, dev, local, d3, N, cpu=True):
     nu, nq, nrev, pb = 28, sk.nq, 12, 4
     fn_b, lm_b = solve_bytes_per_frame_iteration(1, 24, nq, nu, nrev, pb)
     lm_b += 8 * pb * nu * nu                                  # k_lm_step<4> also reads the prior's off-diagonal blocks
-    lr_b = 8 * ((nq + nrev) + 4 * nrev + pb * nu * nu + nu * nu + 2 * nu + 2 * nu + 8)   # k_lr_band: state + Gamma in; 4 blocks out; diagonal block, gradient read-modify-write; cost
+    lr_b = 8 * ((nq + nrev) + pb * nu * nu + 2 * nu * nu + 2 * nu + 1)   # k_lr_band: state in; 4 blocks out; diagonal block and gradient read-modify-write; cost
     ms = {k: v[0] for k, v in prof.items()}; nl = {k: v[1] for k, v in prof.items()}
     lm_ms = ms.get("k_lm_step", 0.0) + ms.get("k_lm_back", 0.0)
     kern = {"k_lm_step<4> + k_lm_back<4>": dict(ms_total=lm_ms, launches=nl.get("k_lm_step", 0), bytes_per_frame_iteration=lm_b,
@@ -432,8 +432,8 @@ def main():
     ap.add_argument("--no-solve", action="store_true")
     ap.add_argument("--no-l24", action="store_true", help="skip the extra 24-marker residual+Jacobian measurement")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 (monocular + learned priors) and config-4 (physics-based) solve timings")
-    ap.add_argument("--cfg3-batch", type=int, default=256)
-    ap.add_argument("--cfg4-batch", type=int, default=128)
+    ap.add_argument("--cfg3-batch", type=int, default=2048, help="sequences of the config-3 timing: 8 launch windows of 256 (one workgroup per CU), a finished sequence hands its slot to the next one")
+    ap.add_argument("--cfg4-batch", type=int, default=512, help="sequences of the config-4 timing (one launch window; 44 GB of node workspace)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the synthetic sequences (0 = as many as the CPU share allows; 1 under a profiler, whose preloaded tool does not survive fork)")
     ap.add_argument("--cfg4-cams", type=int, default=6, choices=(1, 6), help="cameras of the physics-based timing (1 = monocular + pose prior, as the reference runs it)")
     args = ap.parse_args()

@@ -408,7 +408,7 @@ static size_t lds_normal(const DevModel& m, int gmm_k = 0, int gmm_dim = 0, bool
     if (camov < (size_t)22 * m.C) camov = (size_t)22 * m.C;
     size_t n = m.ns + camov + 3 * m.L + 3 * m.sv_n + GAM_STRIDE * m.nrev + (ov > hg ? ov : hg) +
                9 * m.L + 3 * m.mc_total;
-    if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX + gmm_dim * gmm_dim + 2 * gmm_dim * m.nu;
+    if (gmm_k > 0) n += CPE_NX + gmm_k * gmm_dim + CPE_MAX_GMM + CPE_NX;          // x | P_k (x - mu_k) | log p_k | gradient in x
     if (shutter) n += 15 * m.C + 6 * m.L + 6;          // shift | coefficients | rc | Mc per camera, M1 per marker, M2
     return sizeof(double) * n;
 }
@@ -474,6 +474,39 @@ static cpe_status create_impl(cpe_handle* h, const cpe_skeleton* skel, const cpe
                 bool any = false;
                 for (int p2 = 0; p2 < nu; p2++) { P.lr_coefT[f][p2] = priors->lr_coef[p2][f]; any = any || priors->lr_coef[p2][f] != 0.0; }
                 if (any) P.lr_feat[P.lr_nf++] = (uint8_t)f;
+            }
+        }
+        // X' = dx/du: x_k = sign_k (c_k - c_ref), c = the reduced coordinate itself or, for a leg link, theta_B + alpha_c (cost pitch)
+        const DevModel& hm = h->hm;
+        for (int i = 0; i < nu; i++)
+            for (int side = 0; side < 2; side++) {
+                const int kk = side == 0 ? i : hm.rel_ref_u[i];
+                if (kk < 0) continue;
+                const double sgn = side == 0 ? hm.rel_sign_u[i] : -hm.rel_sign_u[i];
+                P.Xc[i][kk] += sgn;
+                const int r = hm.rev_of_u[kk];
+                if (r >= 0) P.Xc[i][hm.rev_body_u[r][1]] += sgn;
+            }
+        // out = X'^T A X' (A, out row-major nu x nu), fixed summation order
+        auto to_u = [&](const double* A, double* out) {
+            std::vector<double> T((size_t)nu * nu);
+            for (int r2 = 0; r2 < nu; r2++)
+                for (int j = 0; j < nu; j++) { double a = 0.0; for (int c = 0; c < nu; c++) a += A[r2 * nu + c] * P.Xc[c][j]; T[(size_t)r2 * nu + j] = a; }
+            for (int i = 0; i < nu; i++)
+                for (int j = 0; j < nu; j++) { double a = 0.0; for (int r2 = 0; r2 < nu; r2++) a += P.Xc[r2][i] * T[(size_t)r2 * nu + j]; out[i * nu + j] = a; }
+        };
+        if (W > 0) {
+            for (int ta = 0; ta <= W; ta++) for (int tb = 0; tb <= ta; tb++) to_u(P.lr_PK[ta][tb], P.lr_PKu[ta][tb]);
+            for (int k = 0; k <= W; k++) to_u(P.lr_HI[k], P.lr_HIu[k]);
+        }
+        if (priors->gmm_k > 0) {
+            const int D = priors->gmm_dim, off = nu - D;
+            std::vector<double> A((size_t)nu * nu);
+            for (int k = 0; k < priors->gmm_k; k++) {
+                std::fill(A.begin(), A.end(), 0.0);
+                for (int i = 0; i < D; i++)
+                    for (int j = 0; j < D; j++) { A[(size_t)(off + i) * nu + off + j] = priors->gmm_P[k][i][j]; P.gmm_PT[k][j][i] = priors->gmm_P[k][i][j]; }
+                to_u(A.data(), P.gmm_Q[k]);
             }
         }
         HIPCHK(hipMalloc(&h->pri, sizeof(DevPriors)));

@@ -148,6 +148,13 @@ struct DevPriors {
     int32_t lr_nf, _pad_nf;
     uint8_t lr_feat[CPE_MAX_WINDOW * CPE_NX];
     double lr_coefT[CPE_MAX_WINDOW * CPE_NX][CPE_NX];
+    // Since the cost pitch the relative angles are LINEAR in the reduced coordinates, x = X' u with a constant X' (entries 0, +-1): every
+    // second-order piece of the two priors is a constant of the model, built once by the host (cpe_api.hip):
+    double Xc[CPE_NX][CPE_NX];                                                         // X' (row = relative angle, column = reduced coordinate)
+    double lr_PKu[CPE_MAX_WINDOW + 1][CPE_MAX_WINDOW + 1][CPE_NX * CPE_NX];            // X'^T lr_PK[ta][tb] X'
+    double lr_HIu[CPE_MAX_WINDOW + 1][CPE_NX * CPE_NX];                                // X'^T lr_HI[k] X'
+    double gmm_PT[CPE_MAX_GMM][CPE_NX][CPE_NX];                                        // gmm_P[k] transposed (consecutive lanes read consecutive words)
+    double gmm_Q[CPE_MAX_GMM][CPE_NX * CPE_NX];                                        // X'_g^T P_k X'_g, X'_g = the rows of X' the pose prior sees
 };
 
 // per-sequence Levenberg-Marquardt state (device global memory)
