@@ -878,6 +878,7 @@ static cpe_status lm_run(cpe_handle* h, int B, int N, const double* q_init, cons
     // in `act` (device arrays; nullptr = all B).  The grids are sized for `slots` sequences; workgroups past *n_act leave at once.
     auto iterate = [&](int first, const int* act, const int* n_act, int slots) {
         const unsigned gf = (unsigned)((size_t)slots * N);
+        const double* hiu = lr ? reinterpret_cast<const double*>(reinterpret_cast<const char*>(h->pri) + offsetof(DevPriors, lr_HIu)) + CPE_NX * CPE_NX : nullptr;
         prof_begin(h, 0);
         hipLaunchKernelGGL(FRAME_NORMAL(h->gmm_k == 0 && sh.tau == nullptr), dim3(gf), dim3(WAVE), ldsn, h->stream, h->dm, h->st, N, first, Fw, h->qbuf, meas, weight, h->gbuf, h->Bbuf,
                            h->costbuf, h->mu, h->gambuf, h->pri, act, n_act, sh);
@@ -890,9 +891,9 @@ static cpe_status lm_run(cpe_handle* h, int B, int N, const double* q_init, cons
         }
         prof_begin(h, 2);
         if (h->pb == 3) hipLaunchKernelGGL((k_lm_step<3, 0>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx, h->dgbuf);
+                                           h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx, h->dgbuf, hiu, h->lr_window);
         else hipLaunchKernelGGL((k_lm_step<4, 0>), dim3(slots), dim3(LM_THREADS), 0, h->stream, h->dm, h->st, prm, first, h->qbuf, h->gbuf, h->Bbuf, h->costbuf,
-                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx, h->dgbuf);
+                                h->Lbuf, h->zbuf, h->gtbuf, h->gambuf, h->Hlr, act, n_act, 2, sh.gx, h->dgbuf, hiu, h->lr_window);
         prof_end(h);
         prof_begin(h, 7);
         if (h->pb == 3) hipLaunchKernelGGL((k_lm_back<3>), dim3(slots), dim3(2 * WAVE), 0, h->stream, h->dm, h->st, prm, h->qbuf, h->Lbuf, h->zbuf, h->gtbuf, h->dgbuf, act, n_act);
