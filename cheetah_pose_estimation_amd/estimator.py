@@ -110,6 +110,39 @@ def load_dlc_table(path: str) -> Tuple[np.ndarray, np.ndarray]:
     return rows[:, 0].astype(np.int64), rows[:, 1:].astype(np.float64)
 
 
+def load_hand_labeled_table(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """One hand-labelled file (`dlc_hand_labeled/cam?.h5`, acinoset_misc.py:1545-1552) in the layout of `load_dlc_table`: (frame index [F], values
+    [F, 75]).  The file holds (x, y) per body part and is indexed by image names (`.../img012.png`): the reference numbers its rows from the
+    digits [3:6] of the first name to those of the last.  Likelihood 1 for a labelled point; a point without a label (NaN) gets likelihood 0 --
+    DEVIATION: the reference compares with `== np.nan` (acinoset_misc.py:221, :247), which is never true, so its NLP would be handed the NaN.
+    `.h5` needs PyTables; the `.csv` twin DeepLabCut writes beside it (`CollectedData_*.csv`: header rows scorer / bodyparts / coords, one or
+    three leading name columns) is read without it."""
+    if path.endswith(".h5"):
+        import pandas as pd
+        df = pd.read_hdf(path)
+        names = [ix[-1] if isinstance(ix, tuple) else str(ix) for ix in df.index]
+        xy = df.to_numpy(dtype=np.float64)
+    else:
+        import csv
+        with open(path, "r", encoding="utf-8", newline="") as f:
+            rows = list(csv.reader(f))
+        coords = rows[2]
+        first = next(i for i, c in enumerate(coords) if c.strip() in ("x", "y"))
+        body = [r for r in rows[3:] if r]
+        names = [r[first - 1] for r in body]
+        xy = np.array([[float(v) if v.strip() not in ("", "nan", "NaN") else np.nan for v in r[first:]] for r in body], dtype=np.float64)
+    base = lambda nm: os.path.basename(str(nm).replace("\\", "/"))
+    start, end = int(base(names[0])[3:6]), int(base(names[-1])[3:6])
+    assert end - start + 1 == xy.shape[0], f"{path}: {xy.shape[0]} rows for frames {start}..{end}"
+    n_parts = xy.shape[1] // 2
+    vals = np.zeros((xy.shape[0], 3 * n_parts))
+    vals[:, 0::3], vals[:, 1::3] = xy[:, 0::2], xy[:, 1::2]
+    ok = np.isfinite(xy[:, 0::2]) & np.isfinite(xy[:, 1::2])
+    vals[:, 2::3] = ok
+    vals[:, 0::3][~ok] = 0.0; vals[:, 1::3][~ok] = 0.0
+    return np.arange(start, end + 1, dtype=np.int64), vals
+
+
 def dlc_paths(dlc_dir: str) -> List[str]:
     h5 = sorted(glob(os.path.join(dlc_dir, "*.h5")))
     try:
@@ -186,11 +219,12 @@ def build_pairwise_measurements(pw_tables, start_frame: int, end_frame: int, syn
     return meas, weight
 
 
-def scene_cameras(scene: Scene, kinetic_dataset: bool):
-    """abi.Camera array from the scene; multipliers [1,1,.6,.6] for the kinetic dataset (acinoset_misc.py:462-464)."""
+def scene_cameras(scene: Scene, kinetic_dataset: bool, hand_labeled: bool = False):
+    """abi.Camera array from the scene; multipliers [1,1,.6,.6] for the kinetic dataset (acinoset_misc.py:462-464) -- not with hand-labelled
+    points, whose squared loss has no multiplier (:471-474)."""
     idx = list(range(scene.n_cams)) if scene.cam_idx is None else [scene.cam_idx]
     cams = (abi.Camera * len(idx))()
-    mult = [1.0, 1.0, 0.6, 0.6] if kinetic_dataset else [1.0] * 6
+    mult = [1.0, 1.0, 0.6, 0.6] if kinetic_dataset and not hand_labeled else [1.0] * 6
     for j, c in enumerate(idx):
         cam = cams[j]
         cam.model = abi.CAM_PINHOLE if kinetic_dataset else abi.CAM_FISHEYE
@@ -439,8 +473,8 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
                     device: int = 0) -> CheetahEstimator:
     """Same signature and meaning as acinoset_opt.init_trajectory (acinoset_opt.py:413-536).  `solver_path`
     (the IPOPT binary of the reference) is accepted and ignored."""
-    if hand_labeled_data:
-        raise NotImplementedError("hand-labelled data (dlc_hand_labeled/*.h5, squared loss) is not built; no stored run of the reference uses it")
+    if hand_labeled_data and enable_ppm:
+        raise NotImplementedError("hand-labelled points together with pairwise predictions (there are none for hand labels)")
     if shutter_delay_estimation and enable_ppm and not monocular_enable:
         raise NotImplementedError("shutter delays together with pairwise predictions: the three measurement slices of a camera would share one delay")
     if cheetah_name not in ("jules", "phantom", "shiraz", "arabia"):
@@ -455,7 +489,7 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
         cam_idx = md["monocular_cam"] if monocular_enable else None
         cam_idx = cam_idx if override_monocular_cam is None else override_monocular_cam
     total_length = end_frame - start_frame
-    dlc_dir = os.path.join(data_dir, "dlc")
+    dlc_dir = os.path.join(data_dir, "dlc_hand_labeled" if hand_labeled_data else "dlc")          # acinoset_opt.py:479
     assert os.path.exists(dlc_dir), dlc_dir
     k_arr, d_arr, r_arr, t_arr, cam_res, n_cams, scene_fpath = find_scene_file(data_dir)
     fps = 200.0
@@ -469,10 +503,19 @@ def init_trajectory(root_dir: str, data_path: str, cheetah_name: str, kinetic_da
     scene = Scene(scene_fpath, k_arr, d_arr, r_arr, t_arr, cam_res, fps, n_cams, cam_idx)
     paths = dlc_paths(dlc_dir)
     assert n_cams == len(paths), f"# of dlc files != # of cams in {scene_fpath}"
-    tables = [load_dlc_table(p) for p in paths]
     sk = skeleton.build_skeleton(model_name, 24, kinetic_dataset)
-    meas, weight = build_measurements(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx, device=device)
-    cams = scene_cameras(scene, kinetic_dataset)
+    if hand_labeled_data:
+        # acinoset_misc.py:217-222, :243-246, :471-474: rows by POSITION n + start_frame of the labelled table, no camera offsets, every labelled point at
+        # weight 1 / R, squared loss (w r)^2.  The kernels evaluate rho(w r) with rho(e) = e^2 / 2 below the first knot: the knots go out of reach
+        # (_kin_prepare) and the weights carry a factor sqrt(2).
+        tables = [load_hand_labeled_table(p) for p in paths]
+        pos = [(np.arange(len(t[0]), dtype=np.int64), t[1]) for t in tables]
+        meas, weight = build_measurements(pos, start_frame, end_frame, None, n_cams, 0.5, kinetic_dataset, cam_idx, device=device)
+        weight = weight * np.sqrt(2.0)
+    else:
+        tables = [load_dlc_table(p) for p in paths]
+        meas, weight = build_measurements(tables, start_frame, end_frame, sync_offset, n_cams, dlc_thresh, kinetic_dataset, cam_idx, device=device)
+    cams = scene_cameras(scene, kinetic_dataset, hand_labeled_data)
     if enable_ppm:
         # m.W = RangeSet(3) (acinoset_misc.py:179): the SAME projected marker is compared with three detections -- its own and two pairwise
         # predictions --, each with its own weight.  For the kernels that is every camera three times with identical parameters: cameras
@@ -524,6 +567,8 @@ def _kin_prepare(est: CheetahEstimator, monocular_constraints: bool, disable_pos
             q_init[:, 3 + 3 * i + 2] = psi[sl]
     opts = options if options is not None else abi.default_options(scene.fps)
     opts.h = 1.0 / scene.fps
+    if params.hand_labeled_data:
+        opts.loss_a, opts.loss_b, opts.loss_c = 1e6, 2e6, 3e6          # squared loss: no residual reaches the first knot (init_trajectory)
     return q_init, opts, pri
 
 
@@ -550,7 +595,7 @@ def _kin_finish(est: CheetahEstimator, h, res: dict, seconds: float, solver_outp
             print("Shutter delay estimation:", [float(v) for v in est.shutter_delay])           # acinoset_opt.py:397-398
     ok = st.status == abi.OK
     if ok:
-        fname = "fte_kinematic"
+        fname = f"fte_kinematic{'_gt' if params.hand_labeled_data else ''}"
         fname = fname if scene.cam_idx is None or monocular_constraints else "fte_kinematic_orig"
         fname = fname if scene.cam_idx is None else f"{fname}_{scene.cam_idx}"    # acinoset_opt.py:626-628
         est.save(fname, out_dir_prefix=out_dir_prefix)
@@ -886,6 +931,8 @@ def estimate_kinetics(estimator: CheetahEstimator, init_torques: bool = True, au
         from . import priors as _priors
         pri = _priors.load_priors(pose=True, motion=False)
     opts = options if options is not None else abi.default_options(scene.fps)
+    if params.hand_labeled_data:
+        opts.loss_a, opts.loss_b, opts.loss_c = 1e6, 2e6, 3e6          # squared loss of hand-labelled points (init_trajectory)
     opts.h = 1.0 / scene.fps
     if options is None:
         opts.tol_cost, opts.max_iter = 1e-6, 1500          # the physics term is stiff: see DESIGN.md 2b (the reference stops IPOPT at Tol = 1e-3; a monocular start with a missed contact window has taken 1 200 iterations)
@@ -984,6 +1031,8 @@ def estimate_grf(estimator: CheetahEstimator, solver_output: bool = True, out_di
                 a, b = int(rec[0][0]) - contact_json["start_frame"], int(rec[0][1]) - contact_json["start_frame"]
                 stance[max(a, 0):max(min(b + 1, N - 1), 0), k] = 1                   # first window only, frames 0 .. N-2 (acinoset_misc.py:954, :1003)
     opts = options if options is not None else abi.default_options(scene.fps)
+    if params.hand_labeled_data:
+        opts.loss_a, opts.loss_b, opts.loss_c = 1e6, 2e6, 3e6          # squared loss of hand-labelled points (init_trajectory)
     opts.h = 1.0 / scene.fps
     if options is None:
         opts.tol_cost, opts.max_iter = 1e-6, 1500

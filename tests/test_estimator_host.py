@@ -167,3 +167,29 @@ def test_measured_plates_are_indexed_by_absolute_frame():
     raw[0][:500] = 0.0                                               # unloaded plate while the DC offset is taken
     P = E.measured_force_plates(raw, direction=-1.0, scale_forces_by=1.0 / 400.0)
     assert P[0].shape == (200, 3) and np.abs(P[0][100] - np.array([-10.0 / 400, 5.0 / 400, 1.0])).max() < 1e-3
+
+
+@pytest.mark.parametrize("name_cols", [1, 3])
+def test_hand_labelled_table_reader(tmp_path, name_cols):
+    """dlc_hand_labeled files (acinoset_misc.py:1545-1552): (x, y) per body part, rows named by image; the reference numbers them from the digits [3:6]
+    of the first and last image names.  Both layouts DeepLabCut has written (one path column; three name columns).  A missing label gets weight 0
+    here (likelihood 0) where the reference's `== np.nan` test never fires."""
+    parts = list(skeleton.DLC_INDEX.keys()) if hasattr(skeleton.DLC_INDEX, "keys") else [f"p{i}" for i in range(25)]
+    parts = sorted(parts, key=lambda m: skeleton.DLC_INDEX[m])
+    rng = np.random.default_rng(3)
+    F, start = 7, 12
+    xy = rng.uniform(0, 1000, (F, 2 * len(parts)))
+    xy[2, 4:6] = np.nan                                                         # body part 2 unlabelled in the third image
+    lead = [""] * (name_cols - 1)
+    rows = [["scorer"] + lead + ["someone"] * xy.shape[1], ["bodyparts"] + lead + [p for p in parts for _ in range(2)], ["coords"] + lead + ["x", "y"] * len(parts)]
+    for i in range(F):
+        nm = ["labeled-data/cam1/img%03d.png" % (start + i)] if name_cols == 1 else ["labeled-data", "cam1", "img%03d.png" % (start + i)]
+        rows.append(nm + ["" if np.isnan(v) else repr(float(v)) for v in xy[i]])
+    p = tmp_path / "cam1.csv"
+    p.write_text("\n".join(",".join(r) for r in rows) + "\n")
+    frames, vals = E.load_hand_labeled_table(str(p))
+    assert np.array_equal(frames, np.arange(start, start + F)) and vals.shape == (F, 3 * len(parts))
+    ok = np.ones((F, len(parts)), bool); ok[2, 2] = False
+    assert np.array_equal(vals[:, 2::3], ok.astype(float))
+    assert np.array_equal(vals[:, 0::3][ok], xy[:, 0::2][ok]) and np.array_equal(vals[:, 1::3][ok], xy[:, 1::2][ok])
+    assert vals[2, 6] == 0.0 and vals[2, 7] == 0.0

@@ -141,6 +141,29 @@ def test_solve_matches_oracle_within_1mm(sk25, cams6, oracle, gpu_handle_factory
         assert np.abs(g).max() < 1e-2 * max(1.0, abs(f)) ** 0.5
 
 
+def test_squared_loss_of_hand_labelled_points_matches_oracle(sk25, cams6, oracle, gpu_handle_factory):
+    """hand_labeled_data=True (acinoset_misc.py:471-474): the measurement cost is (w r)^2 instead of the redescending loss.  The estimator gets it from
+    the same kernels with the knots out of reach and sqrt(2) on the weights (estimator.init_trajectory / _kin_prepare): HIP == oracle under those
+    options, and the reported measurement cost IS sum (w r)^2 of the residuals the solve returns.  Data without gross outliers, as hand labels are
+    (with the 10 % outliers of the other tests a squared loss is dragged 1 rad past the joint ranges and neither implementation converges)."""
+    opts = abi.default_options(); opts.loss_a, opts.loss_b, opts.loss_c = 1e6, 2e6, 3e6
+    h = gpu_handle_factory(sk25, cams6, opts)
+    B, N = 2, 30
+    d = synth.make_batch(sk25, cams6, B=B, N=N, seed=91, outlier_frac=0.0)
+    w2 = d["weight"] * np.sqrt(2.0)
+    out = h.solve_host(d["q_init"], d["meas"], w2)
+    for b in range(B):
+        ref = oracle.solve(sk25, cams6, opts, None, d["q_init"][b], d["meas"][b], w2[b])
+        st = out["stats"][b]
+        assert st.status == abi.OK and ref["stats"].status == abi.OK and abs(st.iterations - ref["stats"].iterations) <= 1
+        assert np.sqrt(((out["positions"][b] - ref["positions"]) ** 2).sum(-1).mean()) < 1e-6
+        assert abs(st.cost - ref["stats"].cost) < 1e-8 * abs(ref["stats"].cost)
+        wr = d["weight"][b][..., None] * out["meas_err"][b]                                   # [N, C, L, 2]
+        assert abs(st.cost_meas - (wr ** 2).sum()) < 1e-9 * st.cost_meas                      # (the terms are reported unscaled, the total times cost_scale)
+        truth = synth.fk_numpy(sk25, d["q_true"][b])[0]
+        assert np.sqrt(((out["positions"][b] - truth) ** 2).sum(-1).mean()) < 2e-2            # 2 px of noise seen from 10 - 20 m: 7 mm
+
+
 def test_randomised_solve_parity_sweep(sk25, cams6, oracle, gpu_handle_factory):
     """48 fresh sequences (seeds 5000..5047, 40 frames, 10 % outliers, 2 px noise) solved in ONE batch on the GPU and one by one
     by the oracle: same status everywhere, marker trajectories far inside the 1 mm bar, iteration counts equal up to the few
@@ -282,6 +305,52 @@ def test_estimator_api_end_to_end_from_files(tmp_path, oracle):
     flags = np.zeros((20, 4), np.int32); flags[2:8, 0] = 1; flags[5:11, 1] = 1; flags[0:4, 3] = 1; flags[14:20, 3] = 1
     oz, oxy, _ = oracle.grf_fit(est.skeleton, gopt, d["q"][:20], d["dq"][:20], d["ddq"][:20], flags)
     assert np.abs(np.array([grfz[f"{n}_foot"] for n in skeleton.FEET]).T - oz).max() < 1e-8
+
+
+def test_hand_labelled_flow_end_to_end_from_files(tmp_path):
+    """init_trajectory(hand_labeled_data=True) -> estimate_kinematics through FILES (acinoset_opt.py:479, :626; acinoset_misc.py:217-246, :471-474):
+    points from `dlc_hand_labeled/`, rows by position, no camera offsets, squared loss, results under `fte_kinematic_gt/`.  The labels written here
+    are the noise-free projections of the planted trajectory with every fifth point unlabelled: the squared-loss solve recovers it to the noise of the
+    initial guess' interpolation."""
+    import os
+    import pickle
+    from cheetah_pose_estimation_amd import estimator as E
+    from dataset_util import write_dataset
+    info = write_dataset(str(tmp_path), N=30)
+    ddir = os.path.join(str(tmp_path), info["data_path"], "dlc_hand_labeled")
+    os.makedirs(ddir)
+    names = [None] * 25
+    for m, i in skeleton.DLC_INDEX.items():
+        names[i] = m
+    names[21] = "unused"
+    rng = np.random.default_rng(2)
+    total = info["q_true"].shape[0]
+    for c in range(6):
+        uv, _ = synth.project_numpy(info["cams"][c], info["pos_true"])
+        with open(os.path.join(ddir, f"cam{c + 1}.csv"), "w") as f:
+            f.write("scorer,,," + ",".join(["hand"] * 50) + "\n")
+            f.write("bodyparts,,," + ",".join(f"{n},{n}" for n in names) + "\n")
+            f.write("coords,,," + ",".join(["x,y"] * 25) + "\n")
+            for n in range(total):
+                vals = [""] * 50
+                for l, m in enumerate(skeleton.MARKERS):
+                    if rng.random() < 0.8:
+                        j = skeleton.DLC_INDEX[m]; vals[2 * j], vals[2 * j + 1] = repr(float(uv[n, l, 0])), repr(float(uv[n, l, 1]))
+                f.write(f"labeled-data,cam{c + 1},img{n:03d}.png," + ",".join(vals) + "\n")
+    est = E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, kinematic_model=True, hand_labeled_data=True)
+    w = est.weight
+    assert 0.7 < (w > 0).mean() < 0.9                                           # the unlabelled points carry no weight
+    sig = skeleton.measurement_sigma(24, False)
+    assert np.allclose(w[w > 0], (np.sqrt(2.0) / sig[None, None, :] * np.ones_like(w))[w > 0])
+    assert E.estimate_kinematics(est, solver_output=False) is True
+    out_dir = os.path.join(str(tmp_path), info["data_path"], "fte_kinematic_gt")
+    with open(os.path.join(out_dir, "fte.pickle"), "rb") as f:      # our own file: plain pickle of numpy arrays
+        d = pickle.load(f)
+    truth = info["pos_true"][info["start"]:info["start"] + 30]
+    assert np.sqrt(((d["positions"] - truth) ** 2).sum(-1).mean()) < 2e-3
+    # measurement cost as the reference defines it: sum (w r)^2 with w = 1 / R
+    wr = (w / np.sqrt(2.0))[..., None] * est.result["meas_err"][0]
+    assert abs(est.costs["measurement"] - (wr ** 2).sum()) < 1e-9 * max(est.costs["measurement"], 1e-12)
 
 
 def test_gpu_fk_and_residual_reproduce_the_reference_stored_2d_files(gpu_handle_factory):

@@ -146,4 +146,4 @@ def test_estimator_with_shutter_delay_estimation(tmp_path):
     with pytest.raises(NotImplementedError):
         E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, kinematic_model=True, shutter_delay_estimation=True, enable_ppm=True)
     with pytest.raises(NotImplementedError):
-        E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, kinematic_model=True, hand_labeled_data=True)
+        E.init_trajectory(str(tmp_path), info["data_path"], "phantom", False, kinematic_model=True, hand_labeled_data=True, enable_ppm=True)
