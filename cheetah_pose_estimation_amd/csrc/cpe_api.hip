@@ -1154,6 +1154,7 @@ static cpe_status build_kin(cpe_handle* h, const cpe_kinetic_options* opt, const
         }
         for (int bl = 0; bl < K.nblk; bl++) {
             const int i = K.blk_i[bl], k = K.blk_k[bl];
+            K.blk_word[bl] = (uint32_t)i | ((uint32_t)k << 8) | ((uint32_t)(uint8_t)K.rel[i][k] << 16) | ((uint32_t)(uint8_t)K.toward[i][k] << 24);
             int nmo = 0, nco = 0;
             for (int mo = 0; mo < K.nm; mo++) {
                 const int a1 = d.motor_first[mo], a2 = d.motor_second[mo];
